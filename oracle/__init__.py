@@ -1,0 +1,15 @@
+"""CPU oracle for the RQAE hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.  rqae_amd/ (the product) never does.
+"""
+from .oracle import (  # noqa: F401
+    build,
+    forward,
+    decode,
+    quantize,
+    max_threads,
+    gemma_norm,
+    gemma_denorm,
+    hook_reference,
+)

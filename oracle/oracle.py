@@ -1,0 +1,160 @@
+"""ctypes front end of librqae_oracle.so (see rqae_oracle.c for what it restates).
+
+TEST INFRASTRUCTURE ONLY -- never imported by rqae_amd/.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librqae_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile rqae_oracle.c with gcc (oracle/Makefile).  Returns the .so path."""
+    src = os.path.join(_HERE, "rqae_oracle.c")
+    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.run(["make", "-s", "-C", _HERE, "-B", "librqae_oracle.so"], check=True)
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = ctypes.CDLL(_SO)
+        fp = ctypes.POINTER(ctypes.c_float)
+        ip = ctypes.POINTER(ctypes.c_int64)
+        bp = ctypes.POINTER(ctypes.c_uint8)
+        i, i64 = ctypes.c_int, ctypes.c_int64
+        lib.rqae_oracle_forward.argtypes = [fp, i64, i, i, i, i, i, fp, fp, fp, fp, fp, fp, ip, fp, i]
+        lib.rqae_oracle_forward.restype = None
+        lib.rqae_oracle_quantize.argtypes = [fp, i64, i, i, fp, fp, ip, fp, i]
+        lib.rqae_oracle_quantize.restype = None
+        lib.rqae_oracle_decode.argtypes = [ip, i64, i, i, i, i, i, fp, fp, fp, bp, fp, i]
+        lib.rqae_oracle_decode.restype = i
+        lib.rqae_oracle_max_threads.restype = i
+        _lib = lib
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def max_threads() -> int:
+    return int(_load().rqae_oracle_max_threads())
+
+
+def forward(x, w, max_layers=None, want_margins=False, want_recon=True, threads=0):
+    """RQAE.forward (rqae/model.py:199-230) on x[..., d]; w = synth.weights()-style dict.
+
+    Returns (q_out[..., d] float32 | None, indices[..., levels] int64[, margins]).
+    """
+    lib = _load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    lead, d = x.shape[:-1], x.shape[-1]
+    L, c, dd = w["w_in"].shape
+    K = w["codebook"].shape[1]
+    assert dd == d
+    levels = L if max_layers is None else int(min(L, max_layers))
+    n = int(np.prod(lead)) if lead else 1
+    xa, xp = _f(x.reshape(n, d))
+    wi, wip = _f(w["w_in"]); bi, bip = _f(w["b_in"]); cb, cbp = _f(w["codebook"])
+    wo, wop = _f(w["w_out"]); bo, bop = _f(w["b_out"])
+    q = np.empty((n, d), np.float32) if want_recon else None
+    idx = np.empty((n, levels), np.int64)
+    mg = np.empty((n, levels), np.float32) if want_margins else None
+    lib.rqae_oracle_forward(
+        xp, n, d, c, K, L, levels, wip, bip, cbp, wop, bop,
+        q.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if want_recon else None,
+        idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+        mg.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if want_margins else None,
+        int(threads))
+    out = (q.reshape(lead + (d,)) if want_recon else None, idx.reshape(lead + (levels,)))
+    if want_margins:
+        out = out + (mg.reshape(lead + (levels,)),)
+    return out
+
+
+def quantize(p, codebook_l, want_margins=False, threads=0):
+    """RQAE.quantize (rqae/model.py:187-197): p[..., c] -> (cv[..., c], idx[...])."""
+    lib = _load()
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    lead, c = p.shape[:-1], p.shape[-1]
+    n = int(np.prod(lead)) if lead else 1
+    K = codebook_l.shape[0]
+    pa, pp = _f(p.reshape(n, c)); cb, cbp = _f(codebook_l)
+    cv = np.empty((n, c), np.float32); idx = np.empty((n,), np.int64)
+    mg = np.empty((n,), np.float32) if want_margins else None
+    lib.rqae_oracle_quantize(pp, n, c, K, cbp, cv.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                             idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                             mg.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if want_margins else None,
+                             int(threads))
+    out = (cv.reshape(lead + (c,)), idx.reshape(lead))
+    if want_margins:
+        out = out + (mg.reshape(lead),)
+    return out
+
+
+def decode(indices, w, layers=None, threads=0):
+    """RQAE.decode (rqae/model.py:250-252): indices[..., NQ] -> q[..., d] or None."""
+    lib = _load()
+    indices = np.ascontiguousarray(indices, dtype=np.int64)
+    lead, nq = indices.shape[:-1], indices.shape[-1]
+    L, c, d = w["w_in"].shape
+    K = w["codebook"].shape[1]
+    n = int(np.prod(lead)) if lead else 1
+    mask = None
+    if layers is not None:
+        mask = np.zeros(L, np.uint8)
+        for l in range(L):
+            if l in layers:
+                mask[l] = 1
+    cb0, cbp = _f(w["codebook"][0]); wo, wop = _f(w["w_out"]); bo, bop = _f(w["b_out"])
+    out = np.empty((n, d), np.float32)
+    used = lib.rqae_oracle_decode(
+        indices.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n, nq, d, c, K, L, cbp, wop, bop,
+        mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)) if mask is not None else None,
+        out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(threads))
+    if used == 0:
+        return None
+    return out.reshape(lead + (d,))
+
+
+# --- the step either side of forward in the real caller (RQAE.hook) -----------------
+
+def gemma_norm(hs, weight, eps=1e-6):
+    """Gemma2 RMSNorm as Gemma2.norm applies it (rqae/llm.py:65-66): fp32
+    x * rsqrt(mean(x^2) + eps) * (1 + w).  numpy float32, op by op."""
+    x = np.asarray(hs, dtype=np.float32)
+    ms = np.mean(x * x, axis=-1, keepdims=True, dtype=np.float32)
+    inv = (np.float32(1.0) / np.sqrt(ms + np.float32(eps))).astype(np.float32)
+    return (x * inv * (np.float32(1.0) + np.asarray(weight, np.float32))).astype(np.float32)
+
+
+def gemma_denorm(q, hs, weight, eps=1e-6):
+    """Gemma2.denorm (rqae/llm.py:68-73): q / (1+w) / rsqrt(mean(hs^2) + eps)."""
+    q = np.asarray(q, np.float32); x = np.asarray(hs, np.float32)
+    q = q / (np.float32(1.0) + np.asarray(weight, np.float32))
+    ms = np.mean(x * x, axis=-1, keepdims=True, dtype=np.float32)
+    inv = (np.float32(1.0) / np.sqrt(ms + np.float32(eps))).astype(np.float32)
+    return (q / inv).astype(np.float32)
+
+
+def hook_reference(hs16, w, norm_weight, skip_bos=True):
+    """What RQAE.hook's hook_fn stores (rqae/model.py:276-289) for fp16 hs[B,S,d]."""
+    hs = np.asarray(hs16).astype(np.float32)
+    normed = gemma_norm(hs, norm_weight)
+    q, idx = forward(normed, w)
+    new = gemma_denorm(q, hs, norm_weight)
+    if skip_bos:
+        new[:, 0] = hs[:, 0]
+    return dict(original=hs, normed=normed, quantized=q, indices=idx, new=new)

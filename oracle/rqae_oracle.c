@@ -1,0 +1,353 @@
+/*
+ * rqae_oracle.c -- CPU restatement of the reference RQAE encode/decode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under rqae_amd/ may import, link or call
+ * this file; it is the checker the HIP path is compared against (tests/,
+ * __graft_entry__.smoke(), and the cpu_baseline leg of bench.py).
+ *
+ * What it restates (all file:line relative to /root/reference):
+ *   forward   rqae/model.py:199-230   level loop: lin_in -> quantize -> STE ->
+ *                                     lin_out -> residual -= / quantized_out +=
+ *   quantize  rqae/model.py:187-197   x/||x|| -> x @ codebook[l].T -> argmax ->
+ *                                     codebook[l][idx]
+ *   argmax    rqae/model.py:180-185   first maximum wins, NaN counts as maximum
+ *   decode    rqae/model.py:232-252   codebook[0][idx] -> sum_l lin_out_l(.)
+ *
+ * Arithmetic is fp32 with every rounding step written out, so that the HIP
+ * kernels can reproduce it bit for bit:
+ *   - x @ codebook.T  : k-ordered fmaf chain from +0   (== ATen mm on CPU, probed)
+ *   - lin_out         : k-ordered fmaf chain from +0, then + bias (== ATen addmm)
+ *   - ||q||           : ATen's vectorised 2-norm order (8-lane fma chunks, one
+ *                       4-chunk of rounded squares, fma tail), then sqrtf
+ *   - q / ||q||       : IEEE division
+ *   - STE             : q + (cv - q), two roundings          (model.py:218-220)
+ *   - lin_in (length-d dot): ATen's blocked GEMM order is not specified, so the
+ *     order is DEFINED here ("canonical order"): d is
+ *     zero-padded to a multiple of 256 and cut into 4 contiguous slices of
+ *     64*P elements; element s*64P + 64*i + lane belongs to (slice s, lane);
+ *     each (slice, lane) runs an fmaf chain over i = 0..P-1 from +0; the 64
+ *     lanes of a slice are summed by the tree in lane_tree(); the slices are
+ *     summed ((s0+s1)+(s2+s3)); the bias is added last.
+ *   The reference's own output differs from this only through that one
+ *   reduction order; parity with it is pinned by the tests/golden fixtures.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -ffp-contract=off -mfma ...).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NSLICE 4
+#define NLANE 64
+
+static inline int pad_dim(int d) { return ((d + 255) / 256) * 256; }
+
+/* Sum of the 64 per-lane partials of one slice.  The pairing mirrors cheap
+ * cross-lane moves on a 64-wide wavefront: lane^32, lane^16, lane^8, mirror
+ * inside each group of 8, lane^1, lane^2.  Every step adds a lane and its
+ * partner (fp32 add is commutative), so both partners hold the same bits. */
+static inline float lane_tree(const float *v)
+{
+    float a[32], b[16], c[8];
+    for (int l = 0; l < 32; ++l) a[l] = v[l] + v[l + 32];
+    for (int l = 0; l < 16; ++l) b[l] = a[l] + a[l + 16];
+    for (int l = 0; l < 8; ++l) c[l] = b[l] + b[l + 8];
+    float u0 = c[0] + c[7], u1 = c[1] + c[6], u2 = c[2] + c[5], u3 = c[3] + c[4];
+    return (u0 + u1) + (u2 + u3);
+}
+
+/* torch.linalg.vector_norm(x, 2) over a contiguous last dim of length c, as the
+ * ATen CPU kernel orders it (rqae/model.py:188 -> x.norm(dim=-1)). */
+static inline float aten_norm2(const float *x, int c)
+{
+    int d = 0;
+    float acc = 0.0f;
+    int n8 = (c / 8) * 8;
+    if (n8) {
+        float buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int d0 = 0; d0 < n8; d0 += 8)
+            for (int j = 0; j < 8; ++j) buf[j] = fmaf(x[d0 + j], x[d0 + j], buf[j]);
+        acc = buf[0];
+        for (int j = 1; j < 8; ++j) acc = acc + buf[j];
+        d = n8;
+    }
+    if (c - d >= 4) {
+        for (int j = 0; j < 4; ++j) {
+            float sq = x[d + j] * x[d + j];
+            acc = acc + sq;
+        }
+        d += 4;
+    }
+    for (; d < c; ++d) acc = fmaf(x[d], x[d], acc);
+    return sqrtf(acc);
+}
+
+/* torch.argmax semantics: a beats b if a > b, or a is NaN and b is not. */
+static inline int beats(float a, float b)
+{
+    return (a > b) || (isnan(a) && !isnan(b));
+}
+
+/* nearest codebook row by cosine similarity; sims is scratch of K floats.
+ * cbT is the level's codebook transposed to [c][K]. */
+static int64_t nearest_row(const float *xn, const float *cbT, int c, int K, float *sims,
+                           float *margin_out)
+{
+    for (int n = 0; n < K; ++n) sims[n] = 0.0f;
+    for (int k = 0; k < c; ++k) {
+        const float xk = xn[k];
+        const float *row = cbT + (size_t)k * K;
+        for (int n = 0; n < K; ++n) sims[n] = fmaf(xk, row[n], sims[n]);
+    }
+    int64_t bidx = 0;
+    float best = sims[0];
+    for (int n = 1; n < K; ++n)
+        if (beats(sims[n], best)) { best = sims[n]; bidx = n; }
+    if (margin_out) {
+        /* top-1 minus the best value strictly below it (duplicates excluded) */
+        float second = -INFINITY;
+        for (int n = 0; n < K; ++n)
+            if (sims[n] < best && sims[n] > second) second = sims[n];
+        *margin_out = isnan(best) ? NAN : best - second;
+    }
+    return bidx;
+}
+
+typedef struct {
+    int d, dp, c, K, L, P;
+    float *w_in;  /* [L][c][dp]  zero padded */
+    float *w_outT;/* [L][c][dp]  transposed + zero padded */
+    float *b_out; /* [L][dp] */
+    float *cbT;   /* [L][c][K] */
+    const float *b_in; /* [L][c] */
+    const float *cb;   /* [L][K][c] */
+} packed_t;
+
+static void pack(packed_t *p, int d, int c, int K, int L, const float *w_in, const float *b_in,
+                 const float *cb, const float *w_out, const float *b_out)
+{
+    p->d = d; p->c = c; p->K = K; p->L = L;
+    p->dp = pad_dim(d); p->P = p->dp / 256;
+    p->b_in = b_in; p->cb = cb;
+    size_t dp = p->dp;
+    p->w_in = (float *)calloc((size_t)L * c * dp, sizeof(float));
+    p->w_outT = (float *)calloc((size_t)L * c * dp, sizeof(float));
+    p->b_out = (float *)calloc((size_t)L * dp, sizeof(float));
+    p->cbT = (float *)calloc((size_t)L * c * K, sizeof(float));
+    for (int l = 0; l < L; ++l) {
+        for (int j = 0; j < c; ++j)
+            memcpy(p->w_in + ((size_t)l * c + j) * dp, w_in + ((size_t)l * c + j) * d,
+                   sizeof(float) * d);
+        for (int e = 0; e < d; ++e) {
+            for (int k = 0; k < c; ++k)
+                p->w_outT[((size_t)l * c + k) * dp + e] = w_out[((size_t)l * d + e) * c + k];
+            p->b_out[(size_t)l * dp + e] = b_out[(size_t)l * d + e];
+        }
+        for (int n = 0; n < K; ++n)
+            for (int k = 0; k < c; ++k)
+                p->cbT[((size_t)l * c + k) * K + n] = cb[((size_t)l * K + n) * c + k];
+    }
+}
+
+static void unpack(packed_t *p)
+{
+    free(p->w_in); free(p->w_outT); free(p->b_out); free(p->cbT);
+}
+
+/* lin_in of one token at one level in the canonical order (see header). */
+static void lin_in_canonical(const packed_t *p, int l, const float *r, float *q)
+{
+    const int P = p->P, dp = p->dp, c = p->c;
+    const int slice_len = NLANE * P;
+    for (int j = 0; j < c; ++j) {
+        const float *w = p->w_in + ((size_t)l * c + j) * dp;
+        float t[NSLICE];
+        for (int s = 0; s < NSLICE; ++s) {
+            float part[NLANE];
+            for (int ln = 0; ln < NLANE; ++ln) part[ln] = 0.0f;
+            const float *rs = r + s * slice_len, *ws = w + s * slice_len;
+            for (int i = 0; i < P; ++i)
+                for (int ln = 0; ln < NLANE; ++ln)
+                    part[ln] = fmaf(rs[64 * i + ln], ws[64 * i + ln], part[ln]);
+            t[s] = lane_tree(part);
+        }
+        q[j] = ((t[0] + t[1]) + (t[2] + t[3])) + p->b_in[(size_t)l * c + j];
+    }
+}
+
+/*
+ * RQAE.forward (rqae/model.py:199-230) on x[n_tokens][d] fp32.
+ *   q_out   [n_tokens][d] fp32 or NULL
+ *   indices [n_tokens][levels] int64
+ *   margins [n_tokens][levels] fp32 or NULL (top-1 minus next distinct value)
+ * levels = min(L, max_layers) is passed by the caller.
+ */
+void rqae_oracle_forward(const float *x, int64_t n_tokens, int d, int c, int K, int L, int levels,
+                         const float *w_in, const float *b_in, const float *cb,
+                         const float *w_out, const float *b_out, float *q_out, int64_t *indices,
+                         float *margins, int n_threads)
+{
+    packed_t p;
+    pack(&p, d, c, K, L, w_in, b_in, cb, w_out, b_out);
+    const int dp = p.dp;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel
+    {
+        float *r = (float *)malloc(sizeof(float) * dp);
+        float *out = (float *)malloc(sizeof(float) * dp);
+        float *y = (float *)malloc(sizeof(float) * dp);
+        float *sims = (float *)malloc(sizeof(float) * K);
+        float *q = (float *)malloc(sizeof(float) * c * 3);
+        float *xn = q + c, *cv = q + 2 * c;
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < n_tokens; ++n) {
+            memcpy(r, x + n * d, sizeof(float) * d);
+            for (int e = d; e < dp; ++e) r[e] = 0.0f;
+            for (int l = 0; l < levels; ++l) {
+                lin_in_canonical(&p, l, r, q);                       /* model.py:211 */
+                const float nrm = aten_norm2(q, c);                    /* model.py:188 */
+                for (int k = 0; k < c; ++k) xn[k] = q[k] / nrm;
+                const float *cbT = p.cbT + (size_t)l * c * K;
+                int64_t idx = nearest_row(xn, cbT, c, K, sims,        /* model.py:190-191 */
+                                          margins ? margins + n * levels + l : NULL);
+                indices[n * levels + l] = idx;
+                const float *row = p.cb + ((size_t)l * K + idx) * c;  /* model.py:192 */
+                for (int k = 0; k < c; ++k) {                          /* model.py:218-220 */
+                    float diff = row[k] - q[k];
+                    cv[k] = q[k] + diff;
+                }
+                for (int e = 0; e < dp; ++e) y[e] = 0.0f;              /* model.py:221 */
+                for (int k = 0; k < c; ++k) {
+                    const float ck = cv[k];
+                    const float *w = p.w_outT + ((size_t)l * c + k) * dp;
+                    for (int e = 0; e < dp; ++e) y[e] = fmaf(ck, w[e], y[e]);
+                }
+                const float *bo = p.b_out + (size_t)l * dp;
+                if (l == 0) {
+                    for (int e = 0; e < dp; ++e) {
+                        float ye = y[e] + bo[e];
+                        r[e] = r[e] - ye;                               /* model.py:223 */
+                        out[e] = 0.0f + ye;                             /* model.py:201,224 */
+                    }
+                } else {
+                    for (int e = 0; e < dp; ++e) {
+                        float ye = y[e] + bo[e];
+                        r[e] = r[e] - ye;
+                        out[e] = out[e] + ye;
+                    }
+                }
+            }
+            if (q_out) memcpy(q_out + n * d, out, sizeof(float) * d);
+        }
+        free(r); free(out); free(y); free(sims); free(q);
+    }
+    unpack(&p);
+}
+
+/*
+ * RQAE.quantize (rqae/model.py:187-197) for one level: pin [n][c] fp32 ->
+ * cv [n][c] (exact codebook rows), idx [n] int64.  cb_l is that level's [K][c].
+ */
+void rqae_oracle_quantize(const float *pin, int64_t n, int c, int K, const float *cb_l, float *cv,
+                          int64_t *idx, float *margins, int n_threads)
+{
+    float *cbT = (float *)malloc(sizeof(float) * c * K);
+    for (int r = 0; r < K; ++r)
+        for (int k = 0; k < c; ++k) cbT[(size_t)k * K + r] = cb_l[(size_t)r * c + k];
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel
+    {
+        float *sims = (float *)malloc(sizeof(float) * K);
+        float *xn = (float *)malloc(sizeof(float) * c);
+#pragma omp for schedule(static)
+        for (int64_t t = 0; t < n; ++t) {
+            const float *q = pin + t * c;
+            const float nrm = aten_norm2(q, c);
+            for (int k = 0; k < c; ++k) xn[k] = q[k] / nrm;
+            int64_t b = nearest_row(xn, cbT, c, K, sims, margins ? margins + t : NULL);
+            idx[t] = b;
+            memcpy(cv + t * c, cb_l + (size_t)b * c, sizeof(float) * c);
+        }
+        free(sims); free(xn);
+    }
+    free(cbT);
+}
+
+/*
+ * RQAE.decode (rqae/model.py:232-252): codebook[0][idx] for every level
+ * (model.py:234), then sum over levels ascending of lin_out_l(cv_l), first
+ * included level assigns, later ones += (model.py:244-247).  level_mask[l]==0
+ * skips level l (the `layers` whitelist); NULL keeps all.  idx is [n][idx_levels].
+ * Levels >= L are ignored like the reference's enumerate(self.layers).
+ * Returns the number of levels summed (0 => reference returns None; out untouched).
+ */
+int rqae_oracle_decode(const int64_t *idx, int64_t n_tokens, int idx_levels, int d, int c, int K,
+                       int L, const float *cb0, const float *w_out, const float *b_out,
+                       const uint8_t *level_mask, float *out, int n_threads)
+{
+    const int dp = pad_dim(d);
+    int used = 0;
+    (void)K;
+    const int lv = idx_levels < L ? idx_levels : L;
+    for (int l = 0; l < lv; ++l)
+        if (!level_mask || level_mask[l]) ++used;
+    if (!used) return 0;
+    float *wT = (float *)calloc((size_t)L * c * dp, sizeof(float));
+    for (int l = 0; l < L; ++l)
+        for (int e = 0; e < d; ++e)
+            for (int k = 0; k < c; ++k)
+                wT[((size_t)l * c + k) * dp + e] = w_out[((size_t)l * d + e) * c + k];
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel
+    {
+        float *acc = (float *)malloc(sizeof(float) * dp);
+        float *y = (float *)malloc(sizeof(float) * dp);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < n_tokens; ++n) {
+            int first = 1;
+            for (int l = 0; l < lv; ++l) {
+                if (level_mask && !level_mask[l]) continue;
+                const float *row = cb0 + (size_t)idx[n * idx_levels + l] * c;
+                for (int e = 0; e < d; ++e) y[e] = 0.0f;
+                for (int k = 0; k < c; ++k) {
+                    const float ck = row[k];
+                    const float *w = wT + ((size_t)l * c + k) * dp;
+                    for (int e = 0; e < d; ++e) y[e] = fmaf(ck, w[e], y[e]);
+                }
+                const float *bo = b_out + (size_t)l * d;
+                if (first) {
+                    for (int e = 0; e < d; ++e) acc[e] = y[e] + bo[e];
+                    first = 0;
+                } else {
+                    for (int e = 0; e < d; ++e) {
+                        float ye = y[e] + bo[e];
+                        acc[e] = acc[e] + ye;
+                    }
+                }
+            }
+            memcpy(out + n * d, acc, sizeof(float) * d);
+        }
+        free(acc); free(y);
+    }
+    free(wT);
+    return used;
+}
+
+int rqae_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

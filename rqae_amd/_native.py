@@ -1,0 +1,207 @@
+"""ctypes binding of the C-ABI library ``librqae_hip.so`` (include/rqae_hip.h).
+
+This is the only route from Python to the HIP kernels.  There is no fallback:
+if the shared library is missing or an entry point fails, a RuntimeError is
+raised.  torch is used here for device memory and the current stream only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "librqae_hip.so")
+
+ABI_VERSION = 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+IDX_I64, IDX_I32, IDX_U16 = 0, 1, 2
+
+# every symbol include/rqae_hip.h declares
+SYMBOLS = (
+    "rqae_hip_abi_version",
+    "rqae_hip_last_error",
+    "rqae_hip_packed_bytes",
+    "rqae_hip_pack",
+    "rqae_hip_encode",
+    "rqae_hip_quantize",
+    "rqae_hip_decode",
+    "rqae_hip_decode_values",
+    "rqae_hip_kernel_info",
+)
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librqae_hip.so once; fail loudly when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise NativeLibraryError(
+            f"{SO_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "rqae_amd has no CPU fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+    L.rqae_hip_abi_version.restype = i
+    L.rqae_hip_last_error.restype = ctypes.c_char_p
+    L.rqae_hip_packed_bytes.argtypes = [i, i, i, i]
+    L.rqae_hip_packed_bytes.restype = sz
+    L.rqae_hip_pack.argtypes = [vp, i, i, i, i, vp, vp, vp, vp, vp, i, vp]
+    L.rqae_hip_pack.restype = i
+    L.rqae_hip_encode.argtypes = [vp, i, i, i, i, vp, i, i64, i, vp, vp, vp]
+    L.rqae_hip_encode.restype = i
+    L.rqae_hip_quantize.argtypes = [vp, i64, i, i, vp, vp, vp, vp]
+    L.rqae_hip_quantize.restype = i
+    L.rqae_hip_decode.argtypes = [vp, i, i, i, i, vp, i, i64, i, vp, vp, vp]
+    L.rqae_hip_decode.restype = i
+    L.rqae_hip_decode_values.argtypes = [vp, i, i, i, i, vp, i64, i, vp, vp, vp]
+    L.rqae_hip_decode_values.restype = i
+    L.rqae_hip_kernel_info.argtypes = [i, i, i, i, ctypes.c_char_p, sz]
+    L.rqae_hip_kernel_info.restype = i
+    if L.rqae_hip_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(
+            f"librqae_hip.so ABI {L.rqae_hip_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().rqae_hip_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"rqae_amd: `{name}` is on {t.device}; the RQAE hot path runs on a ROCm device only "
+            "(no CPU fallback). Move the module and its input to 'cuda'.")
+
+
+_X_DTYPES = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}
+_IDX_DTYPES = {torch.int64: IDX_I64, torch.int32: IDX_I32, torch.uint16: IDX_U16}
+
+
+def packed_bytes(d: int, c: int, K: int, L: int) -> int:
+    return int(lib().rqae_hip_packed_bytes(d, c, K, L))
+
+
+def pack(w_in, b_in, codebook, w_out, b_out, codebook_shared: bool) -> torch.Tensor:
+    """Stacked fp32 parameters -> one device block in the kernels' layout."""
+    L_, c, d = w_in.shape
+    K = codebook.shape[1]
+    for n, t in (("w_in", w_in), ("b_in", b_in), ("codebook", codebook), ("w_out", w_out), ("b_out", b_out)):
+        _require_cuda(t, n)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"pack: {n} must be contiguous float32")
+    nbytes = packed_bytes(d, c, K, L_)
+    if nbytes == 0:
+        _check(1, "rqae_hip_packed_bytes")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w_in.device)
+    with torch.cuda.device(w_in.device):
+        rc = lib().rqae_hip_pack(out.data_ptr(), d, c, K, L_, w_in.data_ptr(), b_in.data_ptr(),
+                                 codebook.data_ptr(), w_out.data_ptr(), b_out.data_ptr(),
+                                 int(bool(codebook_shared)), _stream(w_in.device))
+    _check(rc, "rqae_hip_pack")
+    return out
+
+
+def encode(packed, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True):
+    """x2d [N,d] {f32,bf16,f16} -> (q_out [N,d] f32 | None, indices [N,levels] i64)."""
+    d, c, K, L_ = dims
+    _require_cuda(x2d, "x")
+    if x2d.dtype not in _X_DTYPES:
+        raise RuntimeError(f"encode: unsupported input dtype {x2d.dtype}")
+    if x2d.dim() != 2 or x2d.shape[1] != d or not x2d.is_contiguous():
+        raise RuntimeError("encode: x must be contiguous [N, d]")
+    n = x2d.shape[0]
+    q = torch.empty((n, d), dtype=torch.float32, device=x2d.device) if want_recon else None
+    idx = torch.empty((n, levels), dtype=torch.int64, device=x2d.device)
+    if n == 0:
+        return q, idx
+    with torch.cuda.device(x2d.device):
+        rc = lib().rqae_hip_encode(packed.data_ptr(), d, c, K, L_, x2d.data_ptr(), _X_DTYPES[x2d.dtype],
+                                   n, levels, q.data_ptr() if want_recon else None, idx.data_ptr(),
+                                   _stream(x2d.device))
+    _check(rc, "rqae_hip_encode")
+    return q, idx
+
+
+def quantize(p2d: torch.Tensor, codebook_l: torch.Tensor):
+    """p2d [N,c] f32, codebook_l [K,c] f32 -> (cv [N,c] f32, idx [N] i64)."""
+    _require_cuda(p2d, "x")
+    _require_cuda(codebook_l, "codebook")
+    n, c = p2d.shape
+    K = codebook_l.shape[0]
+    cv = torch.empty((n, c), dtype=torch.float32, device=p2d.device)
+    idx = torch.empty((n,), dtype=torch.int64, device=p2d.device)
+    if n == 0:
+        return cv, idx
+    with torch.cuda.device(p2d.device):
+        rc = lib().rqae_hip_quantize(p2d.data_ptr(), n, c, K, codebook_l.data_ptr(), cv.data_ptr(),
+                                     idx.data_ptr(), _stream(p2d.device))
+    _check(rc, "rqae_hip_quantize")
+    return cv, idx
+
+
+def _mask_arg(level_mask):
+    if level_mask is None:
+        return None, None
+    buf = (ctypes.c_uint8 * len(level_mask))(*[1 if m else 0 for m in level_mask])
+    return buf, ctypes.cast(buf, ctypes.c_void_p)
+
+
+def decode(packed, dims, idx2d: torch.Tensor, level_mask=None) -> torch.Tensor:
+    """idx2d [N,NQ] {i64,i32,u16} -> out [N,d] f32 (sum over unmasked levels)."""
+    d, c, K, L_ = dims
+    _require_cuda(idx2d, "indices")
+    if idx2d.dtype not in _IDX_DTYPES:
+        raise RuntimeError(f"decode: unsupported index dtype {idx2d.dtype}")
+    n, nq = idx2d.shape
+    out = torch.empty((n, d), dtype=torch.float32, device=idx2d.device)
+    if n == 0:
+        return out
+    keep, maskp = _mask_arg(level_mask)
+    with torch.cuda.device(idx2d.device):
+        rc = lib().rqae_hip_decode(packed.data_ptr(), d, c, K, L_, idx2d.data_ptr(), _IDX_DTYPES[idx2d.dtype],
+                                   n, nq, maskp, out.data_ptr(), _stream(idx2d.device))
+    _check(rc, "rqae_hip_decode")
+    return out
+
+
+def decode_values(packed, dims, cv3d: torch.Tensor, level_mask=None) -> torch.Tensor:
+    """cv3d [N,NQ,c] f32 -> out [N,d] f32."""
+    d, c, K, L_ = dims
+    _require_cuda(cv3d, "codebook_values")
+    n, nq, cc = cv3d.shape
+    if cc != c or cv3d.dtype != torch.float32 or not cv3d.is_contiguous():
+        raise RuntimeError("decode_values: codebook_values must be contiguous float32 [N, NQ, c]")
+    out = torch.empty((n, d), dtype=torch.float32, device=cv3d.device)
+    if n == 0:
+        return out
+    keep, maskp = _mask_arg(level_mask)
+    with torch.cuda.device(cv3d.device):
+        rc = lib().rqae_hip_decode_values(packed.data_ptr(), d, c, K, L_, cv3d.data_ptr(), n, nq, maskp,
+                                          out.data_ptr(), _stream(cv3d.device))
+    _check(rc, "rqae_hip_decode_values")
+    return out
+
+
+def kernel_info(d: int, c: int, K: int, L: int) -> str:
+    """Which kernel variant encode() would launch for this shape (for bench/logs)."""
+    buf = ctypes.create_string_buffer(256)
+    rc = lib().rqae_hip_kernel_info(d, c, K, L, buf, 256)
+    _check(rc, "rqae_hip_kernel_info")
+    return buf.value.decode()

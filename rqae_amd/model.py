@@ -1,0 +1,349 @@
+"""Host-side mirror of the reference ``rqae.model.RQAE`` for the MI355X path.
+
+The class keeps the reference's public surface so its callers
+(scripts/1_create_activations.py:144,176; scripts/3_make_rqae_features.py:184;
+rqae/feature.py:95-137; demo/server/server.py:101-112) run unchanged:
+
+* constructor arguments and state-dict keys      -- rqae/model.py:18-73
+* ``forward`` / ``quantize`` / ``decode`` / ``hook`` -- rqae/model.py:187-291
+* cached metadata properties                     -- rqae/model.py:133-178
+
+What differs is where the arithmetic happens: the level loop of ``forward``,
+``quantize`` and ``decode`` are single launches of the gfx950 kernels in
+rqae_amd/csrc behind the C ABI of include/rqae_hip.h.  The hot path is
+inference-only and device-only; it raises instead of falling back to CPU.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from itertools import product
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native
+
+_FSQ_METHODS = ("fsq", "round_fsq")
+
+
+def _fsq_grid(codebook_dim: int, codebook_size: int, unit_rows: bool) -> torch.Tensor:
+    """The (K, c) FSQ lattice in float64 (K = codebook_size ** codebook_dim).
+
+    Same numbers as rqae/model.py:64-71: the Cartesian power of
+    linspace(-1, 1, codebook_size); with ``unit_rows`` each row is scaled to unit
+    L2 norm and the all-zero row (odd codebook_size) stays zero.
+    """
+    axis = np.linspace(-1, 1, codebook_size)
+    lattice = np.array(list(product(axis, repeat=codebook_dim)))
+    if unit_rows:
+        length = np.linalg.norm(lattice, axis=-1, keepdims=True)
+        length = np.where(length == 0, 1.0, length)
+        lattice = np.divide(lattice, length, where=length != 0)
+    return torch.from_numpy(lattice)
+
+
+class RQAE(nn.Module):
+    """Residual-quantisation autoencoder; see module docstring for the mapping."""
+
+    PRETRAINED = {
+        "google/gemma-2-2b": "harish-kamath/rqae/gemma-2-2b",
+        "rqae-rqae-round_fsq-cbd4-cbs5-nq1024": "harish-kamath/rqae/gemma-2-2b",
+    }
+
+    def __init__(self, dim: int = 2304, codebook_dim: int = 4, codebook_size: int = 5,
+                 num_quantizers: int = 1024, quantization_method: str = "round_fsq",
+                 name: str = "", **kwargs):
+        super().__init__()
+        # layers.{l}.0 = lin_in (d -> c), layers.{l}.1 = lin_out (c -> d)
+        self.layers = nn.ModuleList(
+            nn.ModuleList((nn.Linear(dim, codebook_dim), nn.Linear(codebook_dim, dim)))
+            for _ in range(num_quantizers))
+        is_fsq = quantization_method in _FSQ_METHODS
+        rows = codebook_size ** codebook_dim if is_fsq else codebook_size
+        self.codebook = nn.Parameter(torch.randn(num_quantizers, rows, codebook_dim))
+        self.register_buffer("codebook_counts", torch.zeros(num_quantizers, rows), persistent=True)
+
+        self.quantization_method = quantization_method
+        self.num_quantizers = num_quantizers
+        self.codebook_dim = codebook_dim
+        self.codebook_size = codebook_size
+        self.name = name
+        self._dim = dim
+        self._packed = None
+        self._packed_key = None
+
+        self.normalize_codebooks()
+        if is_fsq:
+            grid = _fsq_grid(codebook_dim, codebook_size, quantization_method == "round_fsq")
+            self.codebook.data.copy_(grid)  # float64 -> float32, broadcast over levels
+            self.codebook.requires_grad = False
+
+    # ------------------------------------------------------------------ loading
+    @classmethod
+    def from_pretrained(cls, model_name: str):
+        """HF-hub loader with the reference's repo layout (rqae/model.py:75-99)."""
+        from huggingface_hub import hf_hub_download
+        from safetensors import safe_open
+
+        model_name = cls.PRETRAINED.get(model_name, model_name)
+        user, repo, *sub = model_name.split("/")
+        folder = "/".join(sub)
+        weights_file = hf_hub_download(f"{user}/{repo}", os.path.join(folder, "model.safetensors"))
+        config_file = hf_hub_download(f"{user}/{repo}", os.path.join(folder, "config.json"))
+        with open(config_file, "r") as fh:
+            params = json.load(fh)
+        name = (f"rqae-{repo}-{params['quantization_method']}-cbd{params['codebook_dim']}"
+                f"-cbs{params['codebook_size']}-nq{params['num_quantizers']}")
+        model = cls(**params, name=name)
+        if weights_file.endswith(".safetensors"):
+            with safe_open(weights_file, framework="pt") as fh:
+                state = {k: fh.get_tensor(k) for k in fh.keys()}
+            model.load_state_dict(state, strict=True)
+        elif weights_file.endswith(".pt"):
+            model.load_state_dict(torch.load(weights_file, weights_only=True))
+        else:
+            raise ValueError(f"Unknown file extension for {weights_file}")
+        return model
+
+    # ------------------------------------------------------- packed-weight cache
+    def _apply(self, fn, *args, **kwargs):
+        self._packed = None  # .to()/.cuda()/.float() move or retype the parameters
+        self._drop_metadata_cache()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._packed = None
+        self._drop_metadata_cache()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _drop_metadata_cache(self):
+        for attr in ("_codebook_sims", "_subfeatures", "_subfeature_sims", "_layer_norms"):
+            self.__dict__.pop(attr, None)
+
+    def __getstate__(self):
+        # picklable (scripts/3_make_rqae_features.py:190-192 ships the module over RPC):
+        # the packed device block is a cache, rebuilt on first use.
+        state = self.__dict__.copy()
+        state["_packed"] = None
+        state["_packed_key"] = None
+        return state
+
+    def _dims(self):
+        return (self._dim, self.codebook_dim, self.codebook.shape[1], self.num_quantizers)
+
+    def _weights_key(self):
+        ver = self.codebook._version
+        for lin_in, lin_out in self.layers:
+            ver += lin_in.weight._version + lin_in.bias._version + lin_out.weight._version + lin_out.bias._version
+        return (self.codebook.device, self.codebook.data_ptr(), self.layers[0][0].weight.data_ptr(), ver)
+
+    def packed_weights(self) -> torch.Tensor:
+        """Device block in the kernels' layout (include/rqae_hip.h: rqae_hip_pack).
+
+        Rebuilt when parameters were moved, reloaded or modified in place.
+        """
+        key = self._weights_key()
+        if self._packed is None or self._packed_key != key:
+            dev = self.codebook.device
+            if dev.type != "cuda":
+                raise RuntimeError(
+                    f"rqae_amd: module parameters are on {dev}; the RQAE hot path runs on a ROCm "
+                    "device only (no CPU fallback). Call .to('cuda') first.")
+            with torch.no_grad():
+                w_in = torch.stack([l[0].weight for l in self.layers]).float().contiguous()
+                b_in = torch.stack([l[0].bias for l in self.layers]).float().contiguous()
+                w_out = torch.stack([l[1].weight for l in self.layers]).float().contiguous()
+                b_out = torch.stack([l[1].bias for l in self.layers]).float().contiguous()
+                cb = self.codebook.detach().float().contiguous()
+                if not torch.isfinite(cb).all():
+                    raise RuntimeError("rqae_amd: codebook contains non-finite values")
+                shared = bool((cb == cb[:1]).all())
+                self._packed = _native.pack(w_in, b_in, cb, w_out, b_out, shared)
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------- small mirrors
+    def update_codebook_counts(self, indices):
+        """No-op, as in the reference (rqae/model.py:101-104 returns before any work)."""
+        return None
+
+    def normalize_codebooks(self):
+        """Row-normalise every level's codebook in place unless it is an FSQ lattice
+        (rqae/model.py:126-131)."""
+        if self.quantization_method in _FSQ_METHODS:
+            return
+        cb = self.codebook.data
+        self.codebook.data.copy_(cb / cb.norm(dim=-1, keepdim=True))
+
+    # -------------------------------------------------- cached metadata (not hot)
+    @property
+    def codebook_sims(self):
+        """(K, K) fp16 cosine similarities of the level-0 codebook (rqae/model.py:133-143)."""
+        if "_codebook_sims" not in self.__dict__:
+            if self.quantization_method != "round_fsq":
+                raise ValueError("Codebook sims only supported for round_fsq for now")
+            unit = F.normalize(self.codebook.data.detach().clone()[0], dim=-1)
+            self.__dict__["_codebook_sims"] = (unit @ unit.T).to(torch.float16)
+        return self.__dict__["_codebook_sims"]
+
+    @property
+    def subfeatures(self):
+        """(L, K, d): lin_out_l applied to codebook[l] (rqae/model.py:145-156)."""
+        if "_subfeatures" not in self.__dict__:
+            self.__dict__["_subfeatures"] = torch.stack(
+                [pair[1](self.codebook[l]) for l, pair in enumerate(self.layers)])
+        return self.__dict__["_subfeatures"]
+
+    @property
+    def subfeature_sims(self):
+        """(L, K, K) fp16 cosine similarities between subfeatures (rqae/model.py:158-168)."""
+        if "_subfeature_sims" not in self.__dict__:
+            unit = F.normalize(self.subfeatures, dim=-1)
+            self.__dict__["_subfeature_sims"] = (unit @ unit.transpose(-1, -2)).to(torch.float16)
+        return self.__dict__["_subfeature_sims"]
+
+    @property
+    def layer_norms(self):
+        """(L,) mean column norm of each lin_out weight (rqae/model.py:170-178)."""
+        if "_layer_norms" not in self.__dict__:
+            self.__dict__["_layer_norms"] = torch.tensor(
+                [pair[1].weight.data.norm(dim=0).mean().item() for pair in self.layers],
+                device=self.layers[0][1].weight.device)
+        return self.__dict__["_layer_norms"]
+
+    # ------------------------------------------------------------------ hot path
+    def _deterministic(self, temperature) -> bool:
+        return temperature < 1e-7 or not self.training
+
+    def gumbel_sample(self, cos_sim, temperature=0.0):
+        """argmax over the last dim (rqae/model.py:180-185).  The stochastic
+        gumbel-softmax branch (training with temperature >= 1e-7) is a training
+        feature outside the encode path and is not provided."""
+        if self._deterministic(temperature):
+            return cos_sim.argmax(dim=-1)
+        raise NotImplementedError("rqae_amd: gumbel sampling (training, temperature>0) is out of scope")
+
+    def quantize_gumbel(self, x, layer_idx, temperature=0.0):
+        """x[..., c] -> (nearest unit codebook row by cosine, its index) for one level
+        (rqae/model.py:187-193); one launch of the HIP quantize kernel."""
+        if not self._deterministic(temperature):
+            raise NotImplementedError("rqae_amd: gumbel sampling (training, temperature>0) is out of scope")
+        lead = x.shape[:-1]
+        p = x.reshape(-1, x.shape[-1]).float().contiguous()
+        cv, idx = _native.quantize(p, self.codebook[layer_idx].detach().float().contiguous())
+        return cv.view(*lead, -1), idx.view(*lead)
+
+    def quantize(self, x, layer_idx, temperature=0.0):
+        self.normalize_codebooks()
+        return self.quantize_gumbel(x, layer_idx, temperature)
+
+    def forward(self, x, max_layers: int = float("inf"), temperature=0.0):
+        """Encode: x[B,S,d] -> (quantized_out[B,S,d] f32, indices[B,S,levels] i64).
+
+        Same values as the reference level loop (rqae/model.py:199-230); levels =
+        min(num_quantizers, max_layers).  x may be fp32 (reference), bf16 or fp16
+        (widened exactly to fp32 on load).  One kernel launch.
+        """
+        if not self._deterministic(temperature):
+            raise NotImplementedError("rqae_amd: gumbel sampling (training, temperature>0) is out of scope")
+        if x.dim() != 3:
+            raise RuntimeError(f"RQAE.forward expects x of shape (B, S, dim), got {tuple(x.shape)}")
+        levels = self.num_quantizers if max_layers >= self.num_quantizers else int(math.ceil(max_layers))
+        if levels <= 0:
+            raise RuntimeError("RQAE.forward: max_layers leaves no quantizer to run (stack of an empty list)")
+        B, S, d = x.shape
+        if d != self._dim:
+            raise RuntimeError(f"RQAE.forward: last dim {d} != model dim {self._dim}")
+        self.normalize_codebooks()  # reference does it once per level (rqae/model.py:196)
+        q, idx = _native.encode(self.packed_weights(), self._dims(), x.reshape(B * S, d).contiguous(), levels)
+        idx = idx.view(B, S, levels)
+        self.update_codebook_counts(idx)
+        return q.view(B, S, d), idx
+
+    def encode(self, x, max_layers: int = float("inf")):
+        """Codes only (skips writing the reconstruction): x[B,S,d] -> indices[B,S,levels]."""
+        if x.dim() != 3:
+            raise RuntimeError(f"RQAE.encode expects x of shape (B, S, dim), got {tuple(x.shape)}")
+        levels = self.num_quantizers if max_layers >= self.num_quantizers else int(math.ceil(max_layers))
+        if levels <= 0:
+            raise RuntimeError("RQAE.encode: max_layers leaves no quantizer to run")
+        B, S, d = x.shape
+        self.normalize_codebooks()
+        _, idx = _native.encode(self.packed_weights(), self._dims(), x.reshape(B * S, d).contiguous(), levels,
+                                want_recon=False)
+        return idx.view(B, S, levels)
+
+    def indices_to_codebook_values(self, indices):
+        """[B,S,NQ] -> [B,S,NQ,c] rows of the LEVEL-0 codebook (rqae/model.py:232-234)."""
+        B, S, NQ = indices.shape
+        return self.codebook[0][indices]
+
+    def _level_mask(self, layers, nq):
+        L = self.num_quantizers
+        keep = [layers is None or (l in layers) for l in range(L)]
+        for l in range(L):
+            if keep[l] and l >= nq:  # reference: codebook_values[:, :, l] out of range
+                raise IndexError(f"index {l} is out of bounds for dimension 2 with size {nq}")
+        return keep
+
+    def decode_from_codebook_values(self, codebook_values, layers=None):
+        """Sum over (whitelisted) levels of lin_out_l(cv[:, :, l]) in level order
+        (rqae/model.py:236-248); None when nothing is selected."""
+        B, S, NQ, CD = codebook_values.shape
+        keep = self._level_mask(layers, NQ)
+        if not any(keep):
+            return None
+        out = _native.decode_values(self.packed_weights(), self._dims(),
+                                    codebook_values.reshape(B * S, NQ, CD).float().contiguous(), keep)
+        return out.view(B, S, -1)
+
+    def decode(self, indices, layers=None):
+        """indices[B,S,NQ] -> reconstruction[B,S,d] (rqae/model.py:250-252); one launch."""
+        B, S, NQ = indices.shape
+        keep = self._level_mask(layers, NQ)
+        if not any(keep):
+            return None
+        idx = indices.reshape(B * S, NQ)
+        if idx.dtype not in (torch.int64, torch.int32, torch.uint16):
+            idx = idx.long()
+        out = _native.decode(self.packed_weights(), self._dims(), idx.contiguous(), keep)
+        return out.view(B, S, -1)
+
+    # ----------------------------------------------------------------- LLM hook
+    def hook(self, **kwargs):
+        """Forward-hook factory with the reference's keyword protocol
+        (rqae/model.py:254-291): llm= | norm=,denorm= ; store=, skip_bos=, replace=."""
+        if "llm" in kwargs:
+            llm = kwargs.pop("llm")
+            assert hasattr(llm, "norm") and hasattr(llm, "denorm"), \
+                "RQAE hook requires norm and denorm from LLM"
+            return self.hook(norm=llm.norm, denorm=llm.denorm, **kwargs)
+        if "norm" not in kwargs:
+            raise ValueError("RQAE hook requires norm from LLM")
+        if "denorm" not in kwargs:
+            raise ValueError("RQAE hook requires denorm from LLM")
+        norm, denorm = kwargs["norm"], kwargs["denorm"]
+        store = kwargs.get("store", lambda name, value: None)
+        skip_bos = kwargs.get("skip_bos", True)
+        replace = kwargs.get("replace", True)
+
+        def hook_fn(module, input, output):
+            hs = output[0].float()
+            store("original", hs.detach().clone())
+            normed = norm(hs)
+            store("normed", normed.detach().clone())
+            q_out, codes = self(normed)
+            store("quantized", q_out.detach().clone())
+            store("indices", codes.detach().clone())
+            q_out = denorm(q_out, hs)
+            if skip_bos:
+                q_out[:, 0] = hs[:, 0]
+            store("new", q_out.detach().clone())
+            if replace:
+                output[0].data.copy_(q_out)
+
+        return hook_fn

@@ -1,0 +1,105 @@
+/*
+ * rqae_hip.h -- C ABI of the MI355X (gfx950) RQAE encode/decode library, librqae_hip.so.
+ *
+ * This is the drop-in boundary for the residual-quantisation hot path of
+ * harish-kamath/rqae.  The reference has no FFI: the path lives in one Python
+ * class, rqae/model.py:RQAE.  Each entry point below replaces the arithmetic of
+ * one method of that class; the Python mirror (rqae_amd/model.py) and any other
+ * host language bind these symbols (ctypes / cffi / cgo / JNI all see plain
+ * pointers and sizes; no torch types cross this line).
+ *
+ * Conventions
+ *   - every pointer except `level_mask` is DEVICE memory on the current HIP device
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
+ *     is enqueued on it, nothing synchronises the device, no allocation happens
+ *   - inputs are borrowed and never written; outputs are caller-allocated
+ *   - return 0 on success; non-zero on error, text via rqae_hip_last_error()
+ *   - arithmetic is fp32 in the order fixed by DESIGN.md section 3; integer
+ *     outputs are bit-exact against oracle/rqae_oracle.c
+ *
+ * Shapes:  d = RQAE dim, c = codebook_dim, K = rows per codebook, L = num_quantizers.
+ */
+#ifndef RQAE_HIP_H
+#define RQAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RQAE_HIP_ABI_VERSION 1
+
+/* element type of the activation matrix x */
+enum { RQAE_X_F32 = 0, RQAE_X_BF16 = 1, RQAE_X_F16 = 2 };
+/* element type of a code-index matrix handed to decode */
+enum { RQAE_IDX_I64 = 0, RQAE_IDX_I32 = 1, RQAE_IDX_U16 = 2 };
+
+int rqae_hip_abi_version(void);
+
+/* Last error message of the calling thread ("" if none). */
+const char *rqae_hip_last_error(void);
+
+/*
+ * Parameter block.  The reference keeps L pairs of nn.Linear plus one codebook
+ * Parameter (rqae/model.py:29-54); the kernels want them stacked, zero-padded to
+ * a multiple of 256 along d and lin_out transposed.  rqae_hip_pack builds that
+ * block on the device from the stacked fp32 tensors:
+ *   w_in [L][c][d]  = layers.{l}.0.weight     b_in  [L][c] = layers.{l}.0.bias
+ *   w_out[L][d][c]  = layers.{l}.1.weight     b_out [L][d] = layers.{l}.1.bias
+ *   codebook [L][K][c]  (must be finite)
+ * codebook_shared != 0 asserts that all L codebooks are identical (FSQ methods,
+ * rqae/model.py:63-72), which lets encode stage the codebook in LDS once.
+ * rqae_hip_packed_bytes returns 0 for an unsupported shape (d > 8192, c > 16).
+ */
+size_t rqae_hip_packed_bytes(int d, int c, int K, int L);
+int rqae_hip_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
+                  const float *codebook, const float *w_out, const float *b_out,
+                  int codebook_shared, void *stream);
+
+/*
+ * RQAE.forward  (rqae/model.py:199-230): the level loop
+ *   q = lin_in_l(r); idx = argmax cos(q, codebook_l); cv = q + (codebook_l[idx] - q);
+ *   y = lin_out_l(cv); r -= y; out += y
+ * for l = 0 .. levels-1 (levels = min(L, max_layers)), one launch.
+ *   x        [n_tokens][d]       x_dtype; bf16/f16 are widened exactly to fp32
+ *   q_out    [n_tokens][d] fp32  or NULL for codes only
+ *   indices  [n_tokens][levels]  int64, contiguous (the reference returns the same
+ *                                values as a permuted view, rqae/model.py:226)
+ */
+int rqae_hip_encode(const void *packed, int d, int c, int K, int L, const void *x, int x_dtype,
+                    int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *stream);
+
+/*
+ * RQAE.quantize / quantize_gumbel at temperature 0 (rqae/model.py:187-197):
+ *   p [n][c] fp32, codebook_l [K][c] fp32 -> cv [n][c] = codebook_l[idx], idx [n] int64
+ */
+int rqae_hip_quantize(const float *p, int64_t n, int c, int K, const float *codebook_l, float *cv,
+                      int64_t *idx, void *stream);
+
+/*
+ * RQAE.decode (rqae/model.py:250-252): codebook[0][indices] for every level
+ * (rqae/model.py:234), then the ascending sum of lin_out_l over the levels whose
+ * level_mask[l] != 0 (rqae/model.py:236-248).  level_mask is a HOST array of L
+ * bytes or NULL (= all levels).  Levels >= idx_levels must be masked out.
+ *   indices [n_tokens][idx_levels] idx_dtype      out [n_tokens][d] fp32
+ * It is an error if no level is selected (the reference returns None; the host
+ * mirror handles that case before calling).
+ */
+int rqae_hip_decode(const void *packed, int d, int c, int K, int L, const void *indices,
+                    int idx_dtype, int64_t n_tokens, int idx_levels, const uint8_t *level_mask,
+                    float *out, void *stream);
+
+/* RQAE.decode_from_codebook_values (rqae/model.py:236-248): cv [n_tokens][nq][c] fp32. */
+int rqae_hip_decode_values(const void *packed, int d, int c, int K, int L, const float *cv,
+                           int64_t n_tokens, int nq, const uint8_t *level_mask, float *out,
+                           void *stream);
+
+/* Human-readable name of the encode kernel variant chosen for a shape. */
+int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RQAE_HIP_H */

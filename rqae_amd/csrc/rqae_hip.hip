@@ -1,0 +1,883 @@
+// rqae_hip.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for the RQAE hot path.
+//
+// What runs here (reference file:line relative to /root/reference):
+//   rqae_hip_encode         RQAE.forward level loop            rqae/model.py:199-230
+//   rqae_hip_quantize       RQAE.quantize at temperature 0     rqae/model.py:187-197
+//   rqae_hip_decode[_values] RQAE.decode                       rqae/model.py:232-252
+//
+// Arithmetic contract (restated on the CPU by
+// oracle/rqae_oracle.c, which these kernels match bit for bit):
+//   * everything is fp32, one rounding per written operation; compiled with
+//     -ffp-contract=off, fused multiply-adds appear only as explicit fmaf()
+//   * lin_in  : d is zero-padded to dp = 256*P and cut into 4 slices of 64*P;
+//               element s*64P + 64*i + lane belongs to (slice s, lane); each
+//               (slice, lane) runs a fmaf chain over i from +0; the 64 lanes are
+//               summed by the pairing lane^32, lane^16, lane^8, 7-mirror, lane^1,
+//               lane^2; slices as ((s0+s1)+(s2+s3)); bias last
+//   * ||q||   : ATen's 2-norm order (8-wide fma chunks, one 4-chunk of rounded
+//               squares, fma tail), IEEE sqrt; q/||q|| IEEE division
+//   * cos-sim : k-ordered fmaf chain from +0; argmax = first maximum
+//   * STE     : q + (cv - q);  lin_out: k-ordered fmaf chain from +0, then + bias
+//
+// Work decomposition of the encode kernel: one workgroup owns TG tokens for all
+// levels.  Wave (slice, half) keeps the residual and the running reconstruction of
+// its TPW tokens x 64*P elements in VGPRs for the whole level loop (the N x d
+// residual never goes back to HBM); weights stream from L2 once per level per
+// workgroup; the only exchange per level is c floats per token through LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/rqae_hip.h"
+
+namespace {
+
+constexpr int NSLICE = 4;
+constexpr int MAGIC = 0x52514145;  // "RQAE"
+constexpr int MAX_D = 8192;
+constexpr int MAX_C = 16;
+constexpr int MAX_MASK_LEVELS = 2048;
+constexpr size_t LDS_CODEBOOK_BUDGET = 96 * 1024;
+
+thread_local char g_err[512] = "";
+
+int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+// ---------------------------------------------------------------- packed block
+struct Header {
+    int magic, d, c, K, L, dp, shared_cb, pad;
+};
+
+struct Layout {
+    size_t w_in, w_out, b_out, b_in, cb, total;
+    int dp;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+Layout make_layout(int d, int c, int K, int L)
+{
+    Layout lo;
+    lo.dp = ((d + 255) / 256) * 256;
+    size_t off = 256;
+    lo.w_in = off;  off += align256(sizeof(float) * (size_t)L * c * lo.dp);
+    lo.w_out = off; off += align256(sizeof(float) * (size_t)L * c * lo.dp);
+    lo.b_out = off; off += align256(sizeof(float) * (size_t)L * lo.dp);
+    lo.b_in = off;  off += align256(sizeof(float) * (size_t)L * c);
+    lo.cb = off;    off += align256(sizeof(float) * (size_t)L * K * c);
+    lo.total = off;
+    return lo;
+}
+
+bool shape_ok(int d, int c, int K, int L)
+{
+    return d >= 1 && d <= MAX_D && c >= 1 && c <= MAX_C && K >= 1 && L >= 1;
+}
+
+__global__ void pack_kernel(Header *hdr, Header h, float *w_in_p, float *w_out_p, float *b_out_p,
+                            const float *w_in, const float *w_out, const float *b_out)
+{
+    const size_t n_w = (size_t)h.L * h.c * h.dp;
+    const size_t n_b = (size_t)h.L * h.dp;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_w; i += stride) {
+        const int e = (int)(i % h.dp);
+        const size_t lj = i / h.dp;  // l*c + j
+        const int j = (int)(lj % h.c);
+        const size_t l = lj / h.c;
+        w_in_p[i] = e < h.d ? w_in[lj * h.d + e] : 0.0f;
+        w_out_p[i] = e < h.d ? w_out[(l * h.d + e) * h.c + j] : 0.0f;  // transposed: [l][k][e]
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_b; i += stride) {
+        const int e = (int)(i % h.dp);
+        const size_t l = i / h.dp;
+        b_out_p[i] = e < h.d ? b_out[l * h.d + e] : 0.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = h;
+}
+
+// ------------------------------------------------------------ cross-lane moves
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// DPP controls: row_ror:8 (lane^8 inside a row of 16), row_half_mirror (i <-> 7-i inside 8),
+// quad_perm [1,0,3,2] (lane^1), quad_perm [2,3,0,1] (lane^2)
+constexpr int DPP_ROR8 = 0x128, DPP_HALF_MIRROR = 0x141, DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;
+
+// v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b.  (The builtin's second result is
+// miscompiled by this toolchain, hence asm; s_nop 1 = the VALU-write -> permlane-read hazard.)
+__device__ __forceinline__ void swap32(float &a, float &b)
+{
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// v_permlane16_swap: odd rows (of 16) of a <-> even rows of b
+__device__ __forceinline__ void swap16(float &a, float &b)
+{
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// One halving step of the reduce-scatter: two registers of per-lane partials in, one out.
+// Lanes whose STAGE bit is 0 keep value a (own + partner), the others keep value b.
+template <int STAGE>
+__device__ __forceinline__ float rs_pair(float a, float b, int lane)
+{
+    if constexpr (STAGE == 0) {
+        swap32(a, b);
+        return a + b;
+    } else if constexpr (STAGE == 1) {
+        swap16(a, b);
+        return a + b;
+    } else {
+        constexpr int bit = STAGE == 2 ? 8 : STAGE == 3 ? 4 : STAGE == 4 ? 1 : 2;
+        constexpr int ctrl = STAGE == 2 ? DPP_ROR8 : STAGE == 3 ? DPP_HALF_MIRROR
+                                                  : STAGE == 4 ? DPP_XOR1 : DPP_XOR2;
+        const bool lo = (lane & bit) == 0;
+        const float keep = lo ? a : b;
+        const float give = lo ? b : a;
+        return keep + dpp_mov<ctrl>(give);
+    }
+}
+
+template <int STAGE>
+__device__ __forceinline__ float rs_single(float a)
+{
+    if constexpr (STAGE == 0) {
+        float b = a;
+        swap32(a, b);
+        return a + b;
+    } else if constexpr (STAGE == 1) {
+        float b = a;
+        swap16(a, b);
+        return a + b;
+    } else {
+        constexpr int ctrl = STAGE == 2 ? DPP_ROR8 : STAGE == 3 ? DPP_HALF_MIRROR
+                                                  : STAGE == 4 ? DPP_XOR1 : DPP_XOR2;
+        return a + dpp_mov<ctrl>(a);
+    }
+}
+
+// N per-lane partial sums -> ceil(N/64) registers; register f, lane -> the complete
+// 64-lane sum of value 64*f + rs_value_of_lane(lane) (lanes whose index is >= N hold copies).
+template <int N, int STAGE, int NF>
+struct ReduceScatter {
+    static __device__ __forceinline__ void run(const float (&in)[N], float (&fin)[NF], int lane)
+    {
+        if constexpr (STAGE == 6) {
+            static_assert(N == NF, "six halvings leave ceil(N0/64) registers");
+#pragma unroll
+            for (int f = 0; f < NF; ++f) fin[f] = in[f];
+        } else {
+            constexpr int M = (N + 1) / 2;
+            float out[M];
+#pragma unroll
+            for (int m = 0; m < N / 2; ++m) out[m] = rs_pair<STAGE>(in[2 * m], in[2 * m + 1], lane);
+            if constexpr (N & 1) out[M - 1] = rs_single<STAGE>(in[N - 1]);
+            ReduceScatter<M, STAGE + 1, NF>::run(out, fin, lane);
+        }
+    }
+};
+
+__device__ __forceinline__ int rs_value_of_lane(int lane)
+{
+    return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) |
+           (((lane >> 2) & 1) << 3) | ((lane & 1) << 4) | (((lane >> 1) & 1) << 5);
+}
+
+// ------------------------------------------------------------ per-token scalar math
+// ||q||_2 in ATen's order (see file header); cp = live length (== C unless GEN).
+template <int C>
+__device__ __forceinline__ float aten_norm2(const float (&q)[C], int cp)
+{
+    const int n8 = (cp / 8) * 8;
+    float acc = 0.0f;
+    if (n8) {
+        float buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int d0 = 0; d0 + 8 <= C; d0 += 8)
+            if (d0 + 8 <= n8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) buf[j] = fmaf(q[d0 + j], q[d0 + j], buf[j]);
+            }
+        acc = buf[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) acc = acc + buf[j];
+    }
+    int tail = n8;
+#pragma unroll
+    for (int d0 = 0; d0 + 4 <= C; d0 += 8)
+        if (d0 == n8 && cp - d0 >= 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sq = q[d0 + j] * q[d0 + j];
+                acc = acc + sq;
+            }
+            tail = d0 + 4;
+        }
+#pragma unroll
+    for (int e = 0; e < C; ++e)
+        if (e >= tail && e < cp) acc = fmaf(q[e], q[e], acc);
+    return __builtin_sqrtf(acc);
+}
+
+// Running (best, index) over the codebook rows staged in LDS; lane owns rows lane, lane+64, ...
+// in ascending order and updates on strictly-greater only => first maximum inside the lane.
+template <int C, int TQ>
+__device__ __forceinline__ void scan_rows(const float (&xn)[TQ][C], const float *cb_lds, int rows,
+                                          int row_base, int cp, int lane, float (&best)[TQ],
+                                          int (&bidx)[TQ])
+{
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+        const int row = r0 + lane;
+        if (row < rows) {
+            float cbv[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) cbv[k] = k < cp ? cb_lds[row * cp + k] : 0.0f;
+#pragma unroll
+            for (int tq = 0; tq < TQ; ++tq) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < C; ++k)
+                    if (k < cp) s = fmaf(xn[tq][k], cbv[k], s);
+                if (s > best[tq]) {
+                    best[tq] = s;
+                    bidx[tq] = row_base + row;
+                }
+            }
+        }
+    }
+}
+
+// 64-lane argmax with lowest-index tie rule (rqae/model.py:182: torch.argmax).
+__device__ __forceinline__ void wave_argmax(float &best, int &bidx)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ob > best || (ob == best && oi < bidx)) {
+            best = ob;
+            bidx = oi;
+        }
+    }
+}
+
+__device__ __forceinline__ float load_x(const void *x, int x_dtype, size_t off)
+{
+    if (x_dtype == RQAE_X_F32) return reinterpret_cast<const float *>(x)[off];
+    if (x_dtype == RQAE_X_BF16) {
+        const uint32_t u = reinterpret_cast<const uint16_t *>(x)[off];
+        return __builtin_bit_cast(float, u << 16);
+    }
+    return (float)reinterpret_cast<const _Float16 *>(x)[off];
+}
+
+// All threads of the workgroup copy n floats global -> LDS.
+__device__ __forceinline__ void stage_floats(float *dst, const float *src, int n)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------ encode kernel
+struct EncParams {
+    const float *w_in, *w_out, *b_out, *b_in, *cb;
+    const Header *hdr;
+    const void *x;
+    float *q_out;
+    long long *idx;
+    long long n_tokens;
+    int d, dp, c, K, levels, x_dtype;
+    int kch;  // codebook rows staged in LDS per chunk (multiple of 64, or >= K)
+};
+
+// P  : elements per lane per slice (dp = 256*P)      C : codebook_dim
+// TPW: tokens held by one wave                        NH: token halves (waves = 4*NH)
+// GEN: P and C are upper bounds, the live sizes come from EncParams (slow generic path)
+template <int P, int C, int TPW, int NH, bool RECON, bool GEN>
+__global__ void __launch_bounds__(256 * NH, NH)
+rqae_encode_kernel(const EncParams p)
+{
+    constexpr int NW = NSLICE * NH;
+    constexpr int TG = TPW * NH;
+    constexpr int TQ = (TG + NW - 1) / NW;
+    constexpr int NV = TPW * C;
+    constexpr int NF = (NV + 63) / 64;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *part = smem;                       // [NH][NSLICE][NV]
+    float *cvs = part + NH * NSLICE * NV;     // [TG][C]
+    float *cbl = cvs + ((TG * C + 3) & ~3);   // [kch][cp]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slice = wave & 3;
+    const int half = wave >> 2;
+    const int cp = GEN ? p.c : C;
+    const int Pp = GEN ? p.dp / 256 : P;
+    const int dp = GEN ? p.dp : 256 * P;
+    const int ebase = slice * 64 * Pp + lane;          // element of (i = 0)
+    const long long tok0 = (long long)blockIdx.x * TG;  // first token of the workgroup
+    const long long tokw = tok0 + half * TPW;           // first token of this wave
+
+    const bool shared_cb = p.hdr->shared_cb != 0;
+    const int nchunk = (p.K + p.kch - 1) / p.kch;
+    const bool stage_once = shared_cb && nchunk == 1;
+
+    float r[P][TPW];
+    float out[RECON ? P : 1][RECON ? TPW : 1];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int e = ebase + 64 * i;
+            const long long tok = tokw + t;
+            const bool ok = (!GEN || i < Pp) && e < p.d && tok < p.n_tokens;
+            r[i][t] = ok ? load_x(p.x, p.x_dtype, (size_t)tok * p.d + e) : 0.0f;
+            if constexpr (RECON) out[i][t] = 0.0f;
+        }
+
+    for (int l = 0; l < p.levels; ++l) {
+        // ---- lin_in partials: acc[t*C + j] = sum_i r[i][t] * W_in[l][j][e_i]   (model.py:211)
+        float acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.0f;
+        {
+            const float *wl = p.w_in + (size_t)l * cp * dp + ebase;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                if (GEN && i >= Pp) continue;
+                float w[C];
+#pragma unroll
+                for (int j = 0; j < C; ++j) w[j] = (!GEN || j < cp) ? wl[(size_t)j * dp + 64 * i] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int j = 0; j < C; ++j)
+                        if (!GEN || j < cp) acc[t * C + j] = fmaf(r[i][t], w[j], acc[t * C + j]);
+            }
+        }
+        // ---- 64-lane tree per value, results scattered over lanes, then to LDS
+        {
+            float fin[NF];
+            ReduceScatter<NV, 0, NF>::run(acc, fin, lane);
+            const int v0 = rs_value_of_lane(lane);
+            float *dst = part + (half * NSLICE + slice) * NV;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                if (64 * f + v0 < NV) dst[64 * f + v0] = fin[f];
+        }
+        if (l == 0 ? true : !stage_once) {
+            const int rows = p.kch < p.K ? p.kch : p.K;
+            stage_floats(cbl, p.cb + (size_t)(shared_cb ? 0 : l) * p.K * cp, rows * cp);
+        }
+        __syncthreads();
+
+        // ---- per token: q, ||q||, cosine argmax, STE value            (model.py:187-193, 218-220)
+        {
+            float q[TQ][C], xn[TQ][C], best[TQ];
+            int bidx[TQ];
+#pragma unroll
+            for (int tq = 0; tq < TQ; ++tq) {
+                const int tl = wave * TQ + tq;  // token inside the workgroup
+                const int th = tl / TPW, tt = tl % TPW;
+                const float *ps = part + (size_t)th * NSLICE * NV + tt * C;
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    if ((GEN && j >= cp) || tl >= TG) { q[tq][j] = 0.0f; continue; }
+                    const float s01 = ps[0 * NV + j] + ps[1 * NV + j];
+                    const float s23 = ps[2 * NV + j] + ps[3 * NV + j];
+                    q[tq][j] = (s01 + s23) + p.b_in[l * cp + j];
+                }
+                const float nrm = aten_norm2<C>(q[tq], cp);
+#pragma unroll
+                for (int j = 0; j < C; ++j) xn[tq][j] = q[tq][j] / nrm;
+                best[tq] = -INFINITY;
+                bidx[tq] = 0;
+            }
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const int row_base = ch * p.kch;
+                const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
+                if (ch > 0) {
+                    __syncthreads();
+                    stage_floats(cbl, p.cb + ((size_t)(shared_cb ? 0 : l) * p.K + row_base) * cp, rows * cp);
+                    __syncthreads();
+                }
+                if (wave * TQ < TG) scan_rows<C, TQ>(xn, cbl, rows, row_base, cp, lane, best, bidx);
+            }
+#pragma unroll
+            for (int tq = 0; tq < TQ; ++tq) {
+                const int tl = wave * TQ + tq;
+                if (tl >= TG) continue;
+                wave_argmax(best[tq], bidx[tq]);
+                const float *row = p.cb + ((size_t)(shared_cb ? 0 : l) * p.K + bidx[tq]) * cp;
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < C; ++j)
+                        if (!GEN || j < cp) {
+                            const float diff = row[j] - q[tq][j];
+                            cvs[tl * C + j] = q[tq][j] + diff;
+                        }
+                    const long long tok = tok0 + tl;
+                    if (tok < p.n_tokens) p.idx[tok * p.levels + l] = bidx[tq];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- lin_out, residual and reconstruction update               (model.py:221-224)
+        {
+            float cv[TPW][C];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int k = 0; k < C; ++k) cv[t][k] = cvs[(half * TPW + t) * C + k];
+            const float *wl = p.w_out + (size_t)l * cp * dp + ebase;
+            const float *bl = p.b_out + (size_t)l * dp + ebase;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                if (GEN && i >= Pp) continue;
+                float w[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) w[k] = (!GEN || k < cp) ? wl[(size_t)k * dp + 64 * i] : 0.0f;
+                const float b = bl[64 * i];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    float y = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < C; ++k)
+                        if (!GEN || k < cp) y = fmaf(cv[t][k], w[k], y);
+                    y = y + b;
+                    r[i][t] = r[i][t] - y;
+                    if constexpr (RECON) out[i][t] = out[i][t] + y;  // level 0: 0 + y (model.py:201)
+                }
+            }
+        }
+        // the next level's writes to `part` happen after this level's reads (barrier above);
+        // its reads of `cvs` happen after the barrier that follows the next writes.
+    }
+
+    if constexpr (RECON) {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int e = ebase + 64 * i;
+                const long long tok = tokw + t;
+                if ((!GEN || i < Pp) && e < p.d && tok < p.n_tokens) p.q_out[(size_t)tok * p.d + e] = out[i][t];
+            }
+    }
+}
+
+template <int P, int C, int TPW, int NH, bool GEN>
+int launch_encode(const EncParams &p, hipStream_t stream)
+{
+    constexpr int TG = TPW * NH;
+    constexpr int NV = TPW * C;
+    EncParams q = p;
+    const size_t fixed = sizeof(float) * (NH * NSLICE * NV + ((TG * C + 3) & ~3));
+    int kch = (int)((LDS_CODEBOOK_BUDGET) / (sizeof(float) * p.c));
+    kch = (kch / 64) * 64;
+    if (kch >= p.K) kch = ((p.K + 63) / 64) * 64;
+    q.kch = kch;
+    const int rows = kch < p.K ? kch : p.K;
+    const size_t lds = fixed + sizeof(float) * (size_t)rows * p.c;
+    const long long nblk = (p.n_tokens + TG - 1) / TG;
+    if (nblk > 0x7fffffffLL) return fail("encode: too many tokens for one launch");
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256 * NH), lds, stream, q);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if (p.q_out) return go(rqae_encode_kernel<P, C, TPW, NH, true, GEN>);
+    return go(rqae_encode_kernel<P, C, TPW, NH, false, GEN>);
+}
+
+enum Variant { V_AUTO = 0, V_A = 1, V_B = 2, V_GEN = 3 };
+
+Variant env_variant()
+{
+    const char *s = getenv("RQAE_HIP_VARIANT");
+    if (!s || !*s) return V_AUTO;
+    if (!strcmp(s, "A")) return V_A;
+    if (!strcmp(s, "B")) return V_B;
+    if (!strcmp(s, "GEN")) return V_GEN;
+    return V_AUTO;
+}
+
+// Which instantiation serves (P, c).  Returns a name; launches when p != nullptr.
+const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream, int *rc)
+{
+    const Variant v = env_variant();
+#define RUN(name, ...)                                  \
+    do {                                                \
+        if (p) *rc = launch_encode<__VA_ARGS__>(*p, stream); \
+        return name;                                    \
+    } while (0)
+    if (v != V_GEN) {
+        if (P == 9 && c == 5) {
+            if (v == V_B) RUN("encode<P=9,C=5,TPW=8,NH=2> 8 waves, 16 tokens/WG", 9, 5, 8, 2, false);
+            RUN("encode<P=9,C=5,TPW=16,NH=1> 4 waves, 16 tokens/WG", 9, 5, 16, 1, false);
+        }
+        if (P == 9 && c == 4) RUN("encode<P=9,C=4,TPW=16,NH=1> 4 waves, 16 tokens/WG", 9, 4, 16, 1, false);
+        if (P == 1 && c == 4) RUN("encode<P=1,C=4,TPW=16,NH=1> 4 waves, 16 tokens/WG", 1, 4, 16, 1, false);
+        if (P == 14 && c == 13) RUN("encode<P=14,C=13,TPW=8,NH=1> 4 waves, 8 tokens/WG", 14, 13, 8, 1, false);
+    }
+    if (P <= 8) RUN("encode<generic P<=8,C<=16,TPW=2>", 8, 16, 2, 1, true);
+    RUN("encode<generic P<=32,C<=16,TPW=2>", 32, 16, 2, 1, true);
+#undef RUN
+}
+
+// ---------------------------------------------------------------- quantize kernel
+struct QuantParams {
+    const float *p, *cb;
+    float *cv;
+    long long *idx;
+    long long n;
+    int c, K, kch;
+};
+
+template <int C>
+__global__ void __launch_bounds__(256)
+rqae_quantize_kernel(const QuantParams p)
+{
+    constexpr int TQ = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cp = p.c;
+    const long long tokw = ((long long)blockIdx.x * 4 + wave) * TQ;
+    float q[TQ][C], xn[TQ][C], best[TQ];
+    int bidx[TQ];
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq) {
+        const long long tok = tokw + tq;
+#pragma unroll
+        for (int j = 0; j < C; ++j) q[tq][j] = (j < cp && tok < p.n) ? p.p[tok * cp + j] : 0.0f;
+        const float nrm = aten_norm2<C>(q[tq], cp);
+#pragma unroll
+        for (int j = 0; j < C; ++j) xn[tq][j] = q[tq][j] / nrm;
+        best[tq] = -INFINITY;
+        bidx[tq] = 0;
+    }
+    const int nchunk = (p.K + p.kch - 1) / p.kch;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int row_base = ch * p.kch;
+        const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
+        if (ch > 0) __syncthreads();
+        stage_floats(smem, p.cb + (size_t)row_base * cp, rows * cp);
+        __syncthreads();
+        scan_rows<C, TQ>(xn, smem, rows, row_base, cp, lane, best, bidx);
+    }
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq) {
+        wave_argmax(best[tq], bidx[tq]);
+        const long long tok = tokw + tq;
+        if (tok < p.n) {
+            if (lane == 0) p.idx[tok] = bidx[tq];
+            if (lane < cp) p.cv[tok * cp + lane] = p.cb[(size_t)bidx[tq] * cp + lane];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ decode kernel
+struct DecParams {
+    const float *w_out, *b_out, *cb0;
+    const void *src;  // indices [n][nq] or cv [n][nq][c]
+    float *out;
+    long long n_tokens;
+    int d, dp, c, K, nlev, nq, idx_dtype;
+    uint32_t mask[MAX_MASK_LEVELS / 32];
+};
+
+__device__ __forceinline__ long long load_idx(const void *src, int dt, size_t off)
+{
+    if (dt == RQAE_IDX_I64) return reinterpret_cast<const long long *>(src)[off];
+    if (dt == RQAE_IDX_I32) return reinterpret_cast<const int *>(src)[off];
+    return reinterpret_cast<const uint16_t *>(src)[off];
+}
+
+// One workgroup = 4 waves (one per slice) x TPW tokens; the running sum stays in VGPRs,
+// lin_out weights stream once per workgroup.  LCH levels of codebook values are staged in LDS.
+template <int P, int C, int TPW, bool FROM_IDX, bool GEN>
+__global__ void __launch_bounds__(256)
+rqae_decode_kernel(const DecParams p)
+{
+    constexpr int LCH = 16;
+    __shared__ float cvl[TPW * LCH * C];
+    const int lane = threadIdx.x & 63;
+    const int slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cp = GEN ? p.c : C;
+    const int Pp = GEN ? p.dp / 256 : P;
+    const int dp = GEN ? p.dp : 256 * P;
+    const int ebase = slice * 64 * Pp + lane;
+    const long long tok0 = (long long)blockIdx.x * TPW;
+
+    float acc[P][TPW];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[i][t] = 0.0f;
+    bool first = true;
+
+    for (int l0 = 0; l0 < p.nlev; l0 += LCH) {
+        const int lch = (p.nlev - l0) < LCH ? (p.nlev - l0) : LCH;
+        __syncthreads();
+        for (int u = threadIdx.x; u < TPW * lch; u += blockDim.x) {
+            const int t = u / lch, ll = u % lch, l = l0 + ll;
+            const long long tok = tok0 + t;
+            const bool on = (p.mask[l >> 5] >> (l & 31)) & 1u;
+            if (!on || tok >= p.n_tokens) continue;
+            const float *row;
+            if constexpr (FROM_IDX) {
+                const long long ix = load_idx(p.src, p.idx_dtype, (size_t)tok * p.nq + l);
+                row = p.cb0 + (size_t)ix * cp;  // level-0 codebook for every level (model.py:234)
+            } else {
+                row = reinterpret_cast<const float *>(p.src) + ((size_t)tok * p.nq + l) * cp;
+            }
+            for (int k = 0; k < cp; ++k) cvl[(t * LCH + ll) * C + k] = row[k];
+        }
+        __syncthreads();
+        for (int ll = 0; ll < lch; ++ll) {
+            const int l = l0 + ll;
+            if (!((p.mask[l >> 5] >> (l & 31)) & 1u)) continue;
+            const float *wl = p.w_out + (size_t)l * cp * dp + ebase;
+            const float *bl = p.b_out + (size_t)l * dp + ebase;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                if (GEN && i >= Pp) continue;
+                float w[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) w[k] = (!GEN || k < cp) ? wl[(size_t)k * dp + 64 * i] : 0.0f;
+                const float b = bl[64 * i];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    float y = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < C; ++k)
+                        if (!GEN || k < cp) y = fmaf(cvl[(t * LCH + ll) * C + k], w[k], y);
+                    y = y + b;
+                    acc[i][t] = first ? y : acc[i][t] + y;  // first level assigns (model.py:244-247)
+                }
+            }
+            first = false;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int e = ebase + 64 * i;
+            const long long tok = tok0 + t;
+            if ((!GEN || i < Pp) && e < p.d && tok < p.n_tokens) p.out[(size_t)tok * p.d + e] = acc[i][t];
+        }
+}
+
+template <int P, int C, int TPW, bool GEN>
+int launch_decode(const DecParams &p, bool from_idx, hipStream_t stream)
+{
+    const long long nblk = (p.n_tokens + TPW - 1) / TPW;
+    if (nblk > 0x7fffffffLL) return fail("decode: too many tokens for one launch");
+    if (from_idx)
+        hipLaunchKernelGGL((rqae_decode_kernel<P, C, TPW, true, GEN>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((rqae_decode_kernel<P, C, TPW, false, GEN>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t stream)
+{
+    if (env_variant() != V_GEN) {
+        if (P == 9 && c == 5) return launch_decode<9, 5, 16, false>(p, from_idx, stream);
+        if (P == 9 && c == 4) return launch_decode<9, 4, 16, false>(p, from_idx, stream);
+        if (P == 1 && c == 4) return launch_decode<1, 4, 16, false>(p, from_idx, stream);
+        if (P == 14 && c == 13) return launch_decode<14, 13, 8, false>(p, from_idx, stream);
+    }
+    if (P <= 8) return launch_decode<8, 16, 4, true>(p, from_idx, stream);
+    return launch_decode<32, 16, 4, true>(p, from_idx, stream);
+}
+
+struct PackedView {
+    const Header *hdr;
+    const float *w_in, *w_out, *b_out, *b_in, *cb;
+    int dp;
+};
+
+PackedView view_of(const void *packed, int d, int c, int K, int L)
+{
+    const Layout lo = make_layout(d, c, K, L);
+    const char *b = static_cast<const char *>(packed);
+    PackedView v;
+    v.hdr = reinterpret_cast<const Header *>(b);
+    v.w_in = reinterpret_cast<const float *>(b + lo.w_in);
+    v.w_out = reinterpret_cast<const float *>(b + lo.w_out);
+    v.b_out = reinterpret_cast<const float *>(b + lo.b_out);
+    v.b_in = reinterpret_cast<const float *>(b + lo.b_in);
+    v.cb = reinterpret_cast<const float *>(b + lo.cb);
+    v.dp = lo.dp;
+    return v;
+}
+
+int decode_common(const void *packed, int d, int c, int K, int L, const void *src, bool from_idx,
+                  int idx_dtype, int64_t n_tokens, int nq, const uint8_t *level_mask, float *out,
+                  void *stream)
+{
+    if (!shape_ok(d, c, K, L)) return fail("decode: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    if (!packed || !src || !out) return fail("decode: null pointer");
+    if (n_tokens < 0 || nq < 1) return fail("decode: bad sizes n_tokens=%lld nq=%d", (long long)n_tokens, nq);
+    if (L > MAX_MASK_LEVELS) return fail("decode: L=%d exceeds %d", L, MAX_MASK_LEVELS);
+    if (from_idx && (idx_dtype < RQAE_IDX_I64 || idx_dtype > RQAE_IDX_U16)) return fail("decode: bad idx_dtype %d", idx_dtype);
+    if (n_tokens == 0) return 0;
+    const PackedView v = view_of(packed, d, c, K, L);
+    DecParams p;
+    memset(&p, 0, sizeof(p));
+    int used = 0, top = 0;
+    for (int l = 0; l < L; ++l) {
+        const bool on = level_mask ? level_mask[l] != 0 : l < nq;
+        if (!on) continue;
+        if (l >= nq) return fail("decode: level %d selected but indices hold only %d levels", l, nq);
+        p.mask[l >> 5] |= 1u << (l & 31);
+        ++used;
+        top = l + 1;
+    }
+    if (!used) return fail("decode: no level selected");
+    p.w_out = v.w_out; p.b_out = v.b_out; p.cb0 = v.cb;
+    p.src = src; p.out = out; p.n_tokens = n_tokens;
+    p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.nlev = top; p.nq = nq; p.idx_dtype = idx_dtype;
+    return dispatch_decode(v.dp / 256, c, p, from_idx, static_cast<hipStream_t>(stream));
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int rqae_hip_abi_version(void) { return RQAE_HIP_ABI_VERSION; }
+
+const char *rqae_hip_last_error(void) { return g_err; }
+
+size_t rqae_hip_packed_bytes(int d, int c, int K, int L)
+{
+    if (!shape_ok(d, c, K, L)) {
+        fail("unsupported shape d=%d c=%d K=%d L=%d (need 1<=d<=%d, 1<=c<=%d)", d, c, K, L, MAX_D, MAX_C);
+        return 0;
+    }
+    return make_layout(d, c, K, L).total;
+}
+
+int rqae_hip_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
+                  const float *codebook, const float *w_out, const float *b_out, int codebook_shared,
+                  void *stream)
+{
+    if (!shape_ok(d, c, K, L)) return fail("pack: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    if (!packed || !w_in || !b_in || !codebook || !w_out || !b_out) return fail("pack: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Layout lo = make_layout(d, c, K, L);
+    char *b = static_cast<char *>(packed);
+    Header h = {MAGIC, d, c, K, L, lo.dp, codebook_shared ? 1 : 0, 0};
+    hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<Header *>(b), h,
+                       reinterpret_cast<float *>(b + lo.w_in), reinterpret_cast<float *>(b + lo.w_out),
+                       reinterpret_cast<float *>(b + lo.b_out), w_in, w_out, b_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b + lo.b_in, b_in, sizeof(float) * (size_t)L * c, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + lo.cb, codebook, sizeof(float) * (size_t)L * K * c, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int rqae_hip_encode(const void *packed, int d, int c, int K, int L, const void *x, int x_dtype,
+                    int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *stream)
+{
+    if (!shape_ok(d, c, K, L)) return fail("encode: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    if (!packed || !x || !indices) return fail("encode: null pointer");
+    if (levels < 1 || levels > L) return fail("encode: levels=%d outside 1..%d", levels, L);
+    if (x_dtype < RQAE_X_F32 || x_dtype > RQAE_X_F16) return fail("encode: bad x_dtype %d", x_dtype);
+    if (n_tokens < 0) return fail("encode: negative n_tokens");
+    if (n_tokens == 0) return 0;
+    const PackedView v = view_of(packed, d, c, K, L);
+    EncParams p;
+    memset(&p, 0, sizeof(p));
+    p.w_in = v.w_in; p.w_out = v.w_out; p.b_out = v.b_out; p.b_in = v.b_in; p.cb = v.cb; p.hdr = v.hdr;
+    p.x = x; p.q_out = q_out; p.idx = reinterpret_cast<long long *>(indices);
+    p.n_tokens = n_tokens; p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.levels = levels; p.x_dtype = x_dtype;
+    int rc = 0;
+    dispatch_encode(v.dp / 256, c, &p, static_cast<hipStream_t>(stream), &rc);
+    return rc;
+}
+
+int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen)
+{
+    if (!shape_ok(d, c, K, L)) return fail("kernel_info: unsupported shape");
+    if (!buf || !buflen) return fail("kernel_info: null buffer");
+    int rc = 0;
+    const char *name = dispatch_encode(((d + 255) / 256), c, nullptr, nullptr, &rc);
+    snprintf(buf, buflen, "%s", name);
+    return 0;
+}
+
+int rqae_hip_quantize(const float *pin, int64_t n, int c, int K, const float *codebook_l, float *cv,
+                      int64_t *idx, void *stream)
+{
+    if (c < 1 || c > MAX_C || K < 1) return fail("quantize: unsupported c=%d K=%d", c, K);
+    if (!pin || !codebook_l || !cv || !idx) return fail("quantize: null pointer");
+    if (n < 0) return fail("quantize: negative n");
+    if (n == 0) return 0;
+    QuantParams p;
+    p.p = pin; p.cb = codebook_l; p.cv = cv; p.idx = reinterpret_cast<long long *>(idx);
+    p.n = n; p.c = c; p.K = K;
+    int kch = (int)(LDS_CODEBOOK_BUDGET / (sizeof(float) * c));
+    kch = (kch / 64) * 64;
+    if (kch >= K) kch = ((K + 63) / 64) * 64;
+    p.kch = kch;
+    const int rows = kch < K ? kch : K;
+    const size_t lds = sizeof(float) * (size_t)rows * c;
+    const long long nblk = (n + 15) / 16;
+    if (nblk > 0x7fffffffLL) return fail("quantize: too many rows for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, p);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if (c <= 4) return go(rqae_quantize_kernel<4>);
+    if (c <= 8) return go(rqae_quantize_kernel<8>);
+    return go(rqae_quantize_kernel<16>);
+}
+
+int rqae_hip_decode(const void *packed, int d, int c, int K, int L, const void *indices, int idx_dtype,
+                    int64_t n_tokens, int idx_levels, const uint8_t *level_mask, float *out, void *stream)
+{
+    return decode_common(packed, d, c, K, L, indices, true, idx_dtype, n_tokens, idx_levels, level_mask, out, stream);
+}
+
+int rqae_hip_decode_values(const void *packed, int d, int c, int K, int L, const float *cv, int64_t n_tokens,
+                           int nq, const uint8_t *level_mask, float *out, void *stream)
+{
+    return decode_common(packed, d, c, K, L, cv, false, 0, n_tokens, nq, level_mask, out, stream);
+}
+
+}  // extern "C"

@@ -121,7 +121,7 @@ class RQAE(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def _drop_metadata_cache(self):
-        for attr in ("_codebook_sims", "_subfeatures", "_subfeature_sims", "_layer_norms"):
+        for attr in ("_codebook_sims", "_subfeatures", "_subfeature_sims", "_layer_norms", "_codebook_used"):
             self.__dict__.pop(attr, None)
 
     def __getstate__(self):
@@ -141,6 +141,27 @@ class RQAE(nn.Module):
             ver += lin_in.weight._version + lin_in.bias._version + lin_out.weight._version + lin_out.bias._version
         return (self.codebook.device, self.codebook.data_ptr(), self.layers[0][0].weight.data_ptr(), ver)
 
+    def _stacked(self):
+        w_in = torch.stack([l[0].weight for l in self.layers]).float().contiguous()
+        b_in = torch.stack([l[0].bias for l in self.layers]).float().contiguous()
+        w_out = torch.stack([l[1].weight for l in self.layers]).float().contiguous()
+        b_out = torch.stack([l[1].bias for l in self.layers]).float().contiguous()
+        return w_in, b_in, w_out, b_out
+
+    def _pack(self, codebook: torch.Tensor) -> torch.Tensor:
+        dev = self.codebook.device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                f"rqae_amd: module parameters are on {dev}; the RQAE hot path runs on a ROCm "
+                "device only (no CPU fallback). Call .to('cuda') first.")
+        with torch.no_grad():
+            w_in, b_in, w_out, b_out = self._stacked()
+            cb = codebook.detach().float().contiguous()
+            if not torch.isfinite(cb).all():
+                raise RuntimeError("rqae_amd: codebook contains non-finite values")
+            shared = bool((cb == cb[:1]).all())
+            return _native.pack(w_in, b_in, cb, w_out, b_out, shared)
+
     def packed_weights(self) -> torch.Tensor:
         """Device block in the kernels' layout (include/rqae_hip.h: rqae_hip_pack).
 
@@ -148,23 +169,28 @@ class RQAE(nn.Module):
         """
         key = self._weights_key()
         if self._packed is None or self._packed_key != key:
-            dev = self.codebook.device
-            if dev.type != "cuda":
-                raise RuntimeError(
-                    f"rqae_amd: module parameters are on {dev}; the RQAE hot path runs on a ROCm "
-                    "device only (no CPU fallback). Call .to('cuda') first.")
-            with torch.no_grad():
-                w_in = torch.stack([l[0].weight for l in self.layers]).float().contiguous()
-                b_in = torch.stack([l[0].bias for l in self.layers]).float().contiguous()
-                w_out = torch.stack([l[1].weight for l in self.layers]).float().contiguous()
-                b_out = torch.stack([l[1].bias for l in self.layers]).float().contiguous()
-                cb = self.codebook.detach().float().contiguous()
-                if not torch.isfinite(cb).all():
-                    raise RuntimeError("rqae_amd: codebook contains non-finite values")
-                shared = bool((cb == cb[:1]).all())
-                self._packed = _native.pack(w_in, b_in, cb, w_out, b_out, shared)
+            self._packed = self._pack(self.codebook)
             self._packed_key = key
         return self._packed
+
+    def _packed_for_encode(self, levels: int) -> torch.Tensor:
+        """Parameter block for one forward call.
+
+        FSQ lattices are constants: the cached block.  Any other method renormalises ALL
+        codebooks in place once per level (rqae/model.py:196 -> 126-131), which is not a
+        bit-wise no-op, so level l is quantised against the rows as they stand after l+1
+        renormalisations; the per-level snapshots are packed for this call only and kept
+        in ``_codebook_used`` for inspection.
+        """
+        if self.quantization_method in _FSQ_METHODS:
+            return self.packed_weights()
+        with torch.no_grad():
+            used = self.codebook.data.clone()
+            for l in range(levels):
+                self.normalize_codebooks()
+                used[l] = self.codebook.data[l]
+            self.__dict__["_codebook_used"] = used[:levels].clone()
+            return self._pack(used)
 
     # ------------------------------------------------------------- small mirrors
     def update_codebook_counts(self, indices):
@@ -258,8 +284,8 @@ class RQAE(nn.Module):
         B, S, d = x.shape
         if d != self._dim:
             raise RuntimeError(f"RQAE.forward: last dim {d} != model dim {self._dim}")
-        self.normalize_codebooks()  # reference does it once per level (rqae/model.py:196)
-        q, idx = _native.encode(self.packed_weights(), self._dims(), x.reshape(B * S, d).contiguous(), levels)
+        packed = self._packed_for_encode(levels)
+        q, idx = _native.encode(packed, self._dims(), x.reshape(B * S, d).contiguous(), levels)
         idx = idx.view(B, S, levels)
         self.update_codebook_counts(idx)
         return q.view(B, S, d), idx
@@ -272,8 +298,8 @@ class RQAE(nn.Module):
         if levels <= 0:
             raise RuntimeError("RQAE.encode: max_layers leaves no quantizer to run")
         B, S, d = x.shape
-        self.normalize_codebooks()
-        _, idx = _native.encode(self.packed_weights(), self._dims(), x.reshape(B * S, d).contiguous(), levels,
+        packed = self._packed_for_encode(levels)
+        _, idx = _native.encode(packed, self._dims(), x.reshape(B * S, d).contiguous(), levels,
                                 want_recon=False)
         return idx.view(B, S, levels)
 

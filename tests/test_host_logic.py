@@ -1,0 +1,106 @@
+"""CPU: host-side mirror of the reference interface, the C-ABI symbol table, and the
+no-fallback rule.  No kernel is launched here."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from rqae_amd import RQAE, _native, synth
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rqae_hip.h")).read()
+    declared = set(re.findall(r"\b(rqae_hip_\w+)\s*\(", hdr))
+    assert declared == set(_native.SYMBOLS)
+    lib = ctypes.CDLL(_native.SO_PATH)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert _native.lib().rqae_hip_abi_version() == _native.ABI_VERSION
+
+
+def test_packed_bytes_and_shape_limits():
+    assert _native.packed_bytes(2304, 5, 1024, 8) > 8 * (2 * 5 * 2304 + 2304 + 5 + 1024 * 5) * 4
+    assert _native.lib().rqae_hip_packed_bytes(9000, 5, 10, 1) == 0     # d > 8192
+    assert _native.lib().rqae_hip_packed_bytes(256, 17, 10, 1) == 0     # c > 16
+    assert b"unsupported" in _native.lib().rqae_hip_last_error()
+    assert "TPW=16" in _native.kernel_info(2304, 5, 1024, 8)
+    assert "generic" in _native.kernel_info(512, 6, 300, 5)
+
+
+def test_state_dict_keys_and_ctor_defaults():
+    m = RQAE(dim=32, codebook_dim=2, codebook_size=3, num_quantizers=3)
+    keys = set(m.state_dict().keys())
+    want = {"codebook", "codebook_counts"} | {f"layers.{l}.{i}.{p}" for l in range(3) for i in (0, 1) for p in ("weight", "bias")}
+    assert keys == want
+    assert m.codebook.shape == (3, 9, 2) and not m.codebook.requires_grad
+    assert m.codebook_counts.shape == (3, 9)
+    assert m.layers[0][0].weight.shape == (2, 32) and m.layers[0][1].weight.shape == (32, 2)
+    assert (m.num_quantizers, m.codebook_dim, m.codebook_size, m.quantization_method, m.name) == (3, 2, 3, "round_fsq", "")
+    d = RQAE.__init__.__defaults__
+    assert d[:6] == (2304, 4, 5, 1024, "round_fsq", "")
+    assert RQAE.PRETRAINED["google/gemma-2-2b"] == "harish-kamath/rqae/gemma-2-2b"
+
+
+def test_fsq_codebook_matches_reference_fixture():
+    k = load_golden("kat_quantize")
+    m = RQAE(dim=8, codebook_dim=4, codebook_size=5, num_quantizers=2)
+    assert np.array_equal(m.codebook[0].numpy(), k["codebook"])
+    assert np.array_equal(m.codebook[1].numpy(), k["codebook"])
+    assert np.array_equal(synth.fsq_codebook(4, 5), k["codebook"])
+    plain = RQAE(dim=8, codebook_dim=2, codebook_size=3, num_quantizers=1, quantization_method="fsq")
+    assert plain.codebook[0].abs().max() == 1.0
+    free = RQAE(dim=8, codebook_dim=3, codebook_size=7, num_quantizers=2, quantization_method="vq")
+    assert free.codebook.shape == (2, 7, 3) and free.codebook.requires_grad
+    assert torch.allclose(free.codebook.norm(dim=-1), torch.ones(2, 7), atol=1e-6)
+
+
+def test_metadata_properties_and_pickle():
+    m = RQAE(dim=16, codebook_dim=2, codebook_size=3, num_quantizers=2).eval()
+    assert m.codebook_sims.shape == (9, 9) and m.codebook_sims.dtype == torch.float16
+    assert m.subfeatures.shape == (2, 9, 16)
+    assert m.subfeature_sims.shape == (2, 9, 9) and m.subfeature_sims.dtype == torch.float16
+    assert m.layer_norms.shape == (2,)
+    m2 = pickle.loads(pickle.dumps(m))
+    assert torch.equal(m2.codebook, m.codebook) and m2._packed is None
+    with pytest.raises(ValueError):
+        RQAE(dim=16, codebook_dim=2, codebook_size=3, num_quantizers=1, quantization_method="fsq").codebook_sims
+    assert m.update_codebook_counts(torch.zeros(1, 1, 2)) is None
+
+
+def test_no_cpu_fallback():
+    m = RQAE(dim=256, codebook_dim=4, codebook_size=4, num_quantizers=2).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 256))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.decode(torch.zeros(1, 3, 2, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.quantize(torch.zeros(1, 3, 4), 0)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 256), temperature=0.5)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "rqae_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f
+                assert "librqae_oracle" not in src, f
+
+
+def test_hook_argument_protocol():
+    m = RQAE(dim=16, codebook_dim=2, codebook_size=3, num_quantizers=1)
+    with pytest.raises(ValueError, match="norm"):
+        m.hook(denorm=lambda a, b: a)
+    with pytest.raises(ValueError, match="denorm"):
+        m.hook(norm=lambda a: a)
+    with pytest.raises(AssertionError):
+        m.hook(llm=object())
+    assert callable(m.hook(norm=lambda a: a, denorm=lambda a, b: a))

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the RQAE encode hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--tokens T]
+
+A "step" is one RQAE.forward (codes + reconstruction, depth 8) over one batch of
+synthetic Gemma-2-2B-shaped activations already resident in HBM:
+BASELINE.json configs[1] -- 262144 tokens x d=2304 in bf16, K=1024 (c=5), depth 8.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank encodes
+its own batch of the same size (token-sharded, weights replicated, no collective on
+the data path): weak scaling.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CFG = dict(dim=2304, codebook_dim=5, codebook_size=4, num_quantizers=8)  # K = 4**5 = 1024
+WORKLOAD = "C2: Gemma-2-2B layer-12 residual stream (synthetic), d=2304, K=1024, depth=8, bf16 in"
+
+# algorithmic work per token
+D, C, K, L = 2304, 5, 1024, 8
+BYTES_PER_TOKEN = D * 2 + D * 4 + L * 8                      # bf16 x in, fp32 recon + int64 codes out = 13888
+FLOPS_PER_TOKEN = L * (2 * D * C + 2 * C * K + 2 * C * D + 2 * D)  # 487424
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector) peak
+
+
+def synth_batch(n_tokens, device, seed):
+    """Gemma-like residual rows generated ON DEVICE (no H2D in the bench): N(0,1) x heavy-tailed
+    channel scale, 4 massive channels, RMS-normalised, x (1+w); rounded to bf16."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    d = CFG["dim"]
+    scale = 0.3 + torch.randn(d, device=device, generator=g) ** 2
+    scale[torch.randperm(d, device=device, generator=g)[:4]] *= 30.0
+    w = 0.1 * torch.randn(d, device=device, generator=g)
+    x = torch.empty(n_tokens, d, device=device, dtype=torch.bfloat16)
+    step = 32768
+    for s in range(0, n_tokens, step):
+        z = torch.randn(min(step, n_tokens - s), d, device=device, generator=g) * scale
+        z = z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6) * (1.0 + w)
+        x[s:s + z.shape[0]] = z.to(torch.bfloat16)
+    return x
+
+
+def cpu_baseline(w, target_seconds=12.0):
+    """The CPU oracle (a port of the reference's math, pinned to its golden vectors) timed on
+    this host's cores on a bounded sample of the same workload."""
+    import oracle
+    from rqae_amd import synth
+
+    threads = oracle.max_threads()
+    probe = synth.round_to_bf16(synth.activations(1000, 2048, CFG["dim"]))
+    oracle.forward(probe[:256], w, threads=threads)  # warm
+    t0 = time.perf_counter()
+    oracle.forward(probe, w, threads=threads)
+    rate = 2048 / (time.perf_counter() - t0)
+    n = int(min(262144, max(4096, rate * target_seconds)))
+    n -= n % 1024
+    x = synth.round_to_bf16(synth.activations(1001, n, CFG["dim"]))
+    t0 = time.perf_counter()
+    oracle.forward(x, w, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{n} tokens of the same workload (bf16-rounded synthetic rows, d=2304 K=1024 depth=8), "
+                      f"oracle/rqae_oracle.c with {threads} OpenMP threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tokens", type=int, default=262144, help="tokens per GPU per step")
+    ap.add_argument("--codes-only", action="store_true", help="time RQAE.encode (no reconstruction written)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from rqae_amd import RQAE, _native, synth
+
+    w = synth.weights(1234, CFG["dim"], CFG["codebook_dim"], CFG["num_quantizers"], CFG["codebook_size"])
+    model = RQAE(**CFG).eval()
+    model.load_state_dict(synth.state_dict_from_weights(w), strict=True)
+    model = model.to(device)
+    x = synth_batch(args.tokens, device, seed=1000 + rank).view(1, args.tokens, CFG["dim"])
+    fn = model.encode if args.codes_only else model.forward
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            fn(x)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()          # same stream the kernel is launched on (torch's current stream)
+            fn(x)
+            b.record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_tokens = args.tokens * world * args.steps
+        value = total_tokens / elapsed
+        bytes_tok = (D * 2 + L * 8) if args.codes_only else BYTES_PER_TOKEN
+        tok_per_s_kernel = args.tokens / (kern_ms * 1e-3)
+        tflops = tok_per_s_kernel * FLOPS_PER_TOKEN / 1e12
+        gbs = tok_per_s_kernel * bytes_tok / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath) and not args.codes_only:
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("tokens") == args.tokens:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "tokens encoded/sec, d=2304, K=1024, depth=8",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD, "tokens_per_gpu_per_step": args.tokens,
+                       "outputs": "codes int64" + ("" if args.codes_only else " + reconstruction fp32"),
+                       "sharding": f"token-sharded x{world}, weights replicated, no collective",
+                       "kernel": _native.kernel_info(D, C, K, L)},
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / PEAK_F32_TFLOPS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "flops_per_token": FLOPS_PER_TOKEN,
+                         "hbm_achieved_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "bytes_per_token": bytes_tok},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "../../include/rqae_hip.h"
 
 namespace {
@@ -66,8 +68,8 @@ struct Header {
 };
 
 struct Layout {
-    size_t w_in, w_out, b_out, b_in, cb, total;
-    int dp;
+    size_t w_in, w_out, b_out, b_in, cb, rec_p, total;
+    int dp, qi;  // qi: float4s per lane per element step in a pass record
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -82,6 +84,12 @@ Layout make_layout(int d, int c, int K, int L)
     lo.b_out = off; off += align256(sizeof(float) * (size_t)L * lo.dp);
     lo.b_in = off;  off += align256(sizeof(float) * (size_t)L * c);
     lo.cb = off;    off += align256(sizeof(float) * (size_t)L * K * c);
+    // Pass records for the LDS-staged kernel.  Pass pl (0..L) applies level pl-1 and projects
+    // onto level pl; its weights are one contiguous block, cut into 1-KiB pieces that LDS-DMA
+    // copies verbatim:  rec_p[pl][slice][i][quad][lane][4] with the lane's 2c+1 floats
+    //   { w_out[pl-1][el][0..c-1], b_out[pl-1][el], w_in[pl][0..c-1][el] },  el = slice*64P + 64i + lane
+    lo.qi = (2 * c + 1 + 3) / 4;
+    lo.rec_p = off; off += align256(sizeof(float) * (size_t)(L + 1) * NSLICE * (lo.dp / 256) * lo.qi * 256);
     lo.total = off;
     return lo;
 }
@@ -89,6 +97,32 @@ Layout make_layout(int d, int c, int K, int L)
 bool shape_ok(int d, int c, int K, int L)
 {
     return d >= 1 && d <= MAX_D && c >= 1 && c <= MAX_C && K >= 1 && L >= 1;
+}
+
+// Fill the pass records (see make_layout).  One thread per float.
+__global__ void pack_records_kernel(Header h, int qi, float *rec_p, const float *w_in, const float *w_out,
+                                    const float *b_out)
+{
+    const int P = h.dp / 256;
+    const size_t total = (size_t)(h.L + 1) * NSLICE * P * qi * 256;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += stride) {
+        const int e4 = (int)(u & 3), lane = (int)((u >> 2) & 63);
+        size_t rest = u >> 8;                      // ((pl*4 + slice)*P + i)*qi + quad
+        const int quad = (int)(rest % qi); rest /= qi;
+        const int i = (int)(rest % P); rest /= P;
+        const int slice = (int)(rest & 3);
+        const size_t pl = rest >> 2;
+        const int n = quad * 4 + e4;
+        const int el = slice * 64 * P + 64 * i + lane;
+        float val = 0.0f;
+        if (el < h.d) {
+            if (n < h.c) { if (pl >= 1) val = w_out[((pl - 1) * h.d + el) * h.c + n]; }
+            else if (n == h.c) { if (pl >= 1) val = b_out[(pl - 1) * h.d + el]; }
+            else if (n <= 2 * h.c) { if (pl < (size_t)h.L) val = w_in[(pl * h.c + (n - h.c - 1)) * h.d + el]; }
+        }
+        rec_p[u] = val;
+    }
 }
 
 __global__ void pack_kernel(Header *hdr, Header h, float *w_in_p, float *w_out_p, float *b_out_p,
@@ -138,15 +172,22 @@ __device__ __forceinline__ void swap16(float &a, float &b)
 
 // One halving step of the reduce-scatter: two registers of per-lane partials in, one out.
 // Lanes whose STAGE bit is 0 keep value a (own + partner), the others keep value b.
-template <int STAGE>
+template <int OP>
+__device__ __forceinline__ float rs_op(float a, float b)
+{
+    if constexpr (OP == 0) return a + b;
+    else return fmaxf(a, b);
+}
+
+template <int STAGE, int OP = 0>
 __device__ __forceinline__ float rs_pair(float a, float b, int lane)
 {
     if constexpr (STAGE == 0) {
         swap32(a, b);
-        return a + b;
+        return rs_op<OP>(a, b);
     } else if constexpr (STAGE == 1) {
         swap16(a, b);
-        return a + b;
+        return rs_op<OP>(a, b);
     } else {
         constexpr int bit = STAGE == 2 ? 8 : STAGE == 3 ? 4 : STAGE == 4 ? 1 : 2;
         constexpr int ctrl = STAGE == 2 ? DPP_ROR8 : STAGE == 3 ? DPP_HALF_MIRROR
@@ -154,31 +195,31 @@ __device__ __forceinline__ float rs_pair(float a, float b, int lane)
         const bool lo = (lane & bit) == 0;
         const float keep = lo ? a : b;
         const float give = lo ? b : a;
-        return keep + dpp_mov<ctrl>(give);
+        return rs_op<OP>(keep, dpp_mov<ctrl>(give));
     }
 }
 
-template <int STAGE>
+template <int STAGE, int OP = 0>
 __device__ __forceinline__ float rs_single(float a)
 {
     if constexpr (STAGE == 0) {
         float b = a;
         swap32(a, b);
-        return a + b;
+        return rs_op<OP>(a, b);
     } else if constexpr (STAGE == 1) {
         float b = a;
         swap16(a, b);
-        return a + b;
+        return rs_op<OP>(a, b);
     } else {
         constexpr int ctrl = STAGE == 2 ? DPP_ROR8 : STAGE == 3 ? DPP_HALF_MIRROR
                                                   : STAGE == 4 ? DPP_XOR1 : DPP_XOR2;
-        return a + dpp_mov<ctrl>(a);
+        return rs_op<OP>(a, dpp_mov<ctrl>(a));
     }
 }
 
 // N per-lane partial sums -> ceil(N/64) registers; register f, lane -> the complete
 // 64-lane sum of value 64*f + rs_value_of_lane(lane) (lanes whose index is >= N hold copies).
-template <int N, int STAGE, int NF>
+template <int N, int STAGE, int NF, int OP = 0>
 struct ReduceScatter {
     static __device__ __forceinline__ void run(const float (&in)[N], float (&fin)[NF], int lane)
     {
@@ -190,9 +231,9 @@ struct ReduceScatter {
             constexpr int M = (N + 1) / 2;
             float out[M];
 #pragma unroll
-            for (int m = 0; m < N / 2; ++m) out[m] = rs_pair<STAGE>(in[2 * m], in[2 * m + 1], lane);
-            if constexpr (N & 1) out[M - 1] = rs_single<STAGE>(in[N - 1]);
-            ReduceScatter<M, STAGE + 1, NF>::run(out, fin, lane);
+            for (int m = 0; m < N / 2; ++m) out[m] = rs_pair<STAGE, OP>(in[2 * m], in[2 * m + 1], lane);
+            if constexpr (N & 1) out[M - 1] = rs_single<STAGE, OP>(in[N - 1]);
+            ReduceScatter<M, STAGE + 1, NF, OP>::run(out, fin, lane);
         }
     }
 };
@@ -299,7 +340,7 @@ __device__ __forceinline__ void stage_floats(float *dst, const float *src, int n
 
 // ------------------------------------------------------------------ encode kernel
 struct EncParams {
-    const float *w_in, *w_out, *b_out, *b_in, *cb;
+    const float *w_in, *w_out, *b_out, *b_in, *cb, *rec_p;
     const Header *hdr;
     const void *x;
     float *q_out;
@@ -307,6 +348,7 @@ struct EncParams {
     long long n_tokens;
     int d, dp, c, K, levels, x_dtype;
     int kch;  // codebook rows staged in LDS per chunk (multiple of 64, or >= K)
+    int ablate;  // RQAE_HIP_ABLATE bits: timing experiments only, results are wrong when != 0
 };
 
 // P  : elements per lane per slice (dp = 256*P)      C : codebook_dim
@@ -487,6 +529,364 @@ rqae_encode_kernel(const EncParams p)
     }
 }
 
+
+
+// ---- token-tile load/store for the fused kernel: lane e-offsets 64*i are immediates, the
+// dtype switch and the bounds predicates are hoisted out of the element loops
+template <typename XT>
+__device__ __forceinline__ float widen(XT v);
+template <>
+__device__ __forceinline__ float widen<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float widen<uint16_t>(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+template <>
+__device__ __forceinline__ float widen<_Float16>(_Float16 v) { return (float)v; }
+
+template <int P, int TPW, typename XT, bool FULL>
+__device__ __forceinline__ void load_tile(float (&dst)[P][TPW], const XT *x, long long tokw, long long n_tokens,
+                                          int d, int ebase)
+{
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const long long tok = tokw + t;
+        const XT *xp = x + (size_t)(FULL ? tok : (tok < n_tokens ? tok : 0)) * d + ebase;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            if constexpr (FULL) dst[i][t] = widen<XT>(xp[64 * i]);
+            else dst[i][t] = (tok < n_tokens && ebase + 64 * i < d) ? widen<XT>(xp[64 * i]) : 0.0f;
+        }
+    }
+}
+
+
+// =============================================================== LDS-staged encode kernel
+// Same arithmetic as rqae_encode_kernel, organised for throughput (exact shapes, d = 256*P):
+//   * 8 waves = 4 slices x 2 token halves, 8 tokens per wave, 16 tokens per workgroup; the
+//     residual and the reconstruction of a wave (2 x 72 VGPRs at P = 9) stay in the 256
+//     VALU-addressable registers for all levels (AGPRs are not VALU operands on gfx950)
+//   * lin_out(l), r -= y, out += y and lin_in(l+1) are ONE pass over those registers, in packed
+//     fp32 math over token pairs (v_pk_fma_f32 / v_pk_add_f32)
+//   * a pass's weights (one record, make_layout) are copied L2 -> LDS by LDS-DMA while the
+//     quantise phase of the previous level runs, and read back with ds_read_b128; both token
+//     halves share them, so each weight byte crosses the CU's L1/TA once per level
+//   * the quantise phase is lane-parallel: lane (token, j) owns q[token][j] (one IEEE divide per
+//     lane), unit vectors reach every lane as scalars (v_readlane), codebook rows come from LDS
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float lane_bcast(float v, int src_lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+__device__ __forceinline__ float lane_bcast_first(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+// 1 KiB per wave-instruction, global -> LDS without touching VGPRs; lds_piece is wave-uniform
+__device__ __forceinline__ void dma_1k(const float *g_lane, float *lds_piece)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
+                                     (__attribute__((address_space(3))) void *)lds_piece, 16, 0, 0);
+}
+
+template <int P, int C, bool RECON>
+__global__ void __launch_bounds__(512, 2)
+rqae_encode_lds_kernel(const EncParams p)
+{
+    constexpr int TPW = 8, NW = 8, TG = 16, TQ = 2, JW = 8, NG = 2, NPAIR = 4;
+    static_assert(C <= 8, "quantise phase uses 8 lanes per token");
+    constexpr int QI = (2 * C + 1 + 3) / 4;
+    constexpr int NPIECE = NSLICE * P * QI;     // 1-KiB pieces in one pass record
+    constexpr int WFLOATS = NPIECE * 256;
+    constexpr int dp = 256 * P;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wts = smem;                       // [slice][i][quad][lane][4]
+    float *part = wts + WFLOATS;             // [NSLICE][TG][C]
+    float *cvs = part + NSLICE * TG * C;     // [C][TG]  (token pairs contiguous)
+    float *cbl = cvs + ((TG * C + 3) & ~3);  // [kch][C]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slice = wave & 3;
+    const int half = wave >> 2;
+    const int ebase = slice * 64 * P + lane;
+    const long long tok0 = (long long)blockIdx.x * TG;
+    const long long tokw = tok0 + half * TPW;
+
+    const bool shared_cb = p.hdr->shared_cb != 0;
+    const int nchunk = (p.K + p.kch - 1) / p.kch;
+    const bool stage_once = shared_cb && nchunk == 1;
+
+    // quantise-phase role of this lane: lanes 0..7 -> token 2*wave, lanes 8..15 -> token 2*wave+1
+    const int tq = lane / JW, jj = lane % JW;
+    const int tl_q = wave * TQ + (tq < TQ ? tq : 0);
+    const bool act = tq < TQ && jj < C;
+
+    auto issue_dma = [&](int pl) {           // the record of pass pl -> wts (all 8 waves share the work)
+        const float *src = p.rec_p + (size_t)pl * WFLOATS + lane * 4;
+        for (int pc = wave; pc < NPIECE; pc += NW) dma_1k(src + pc * 256, wts + pc * 256);
+    };
+
+    issue_dma(0);
+    {
+        const int rows = p.kch < p.K ? p.kch : p.K;
+        stage_floats(cbl, p.cb, rows * C);
+    }
+
+    f2 r2[P][NPAIR];
+    f2 out2[RECON ? P : 1][RECON ? NPAIR : 1];
+    const bool full_tile = (tokw + TPW <= p.n_tokens) && (p.d == dp);  // wave-uniform
+    {
+        float xt[P][TPW];
+        if (full_tile) {
+            if (p.x_dtype == RQAE_X_BF16) load_tile<P, TPW, uint16_t, true>(xt, (const uint16_t *)p.x, tokw, p.n_tokens, p.d, ebase);
+            else if (p.x_dtype == RQAE_X_F32) load_tile<P, TPW, float, true>(xt, (const float *)p.x, tokw, p.n_tokens, p.d, ebase);
+            else load_tile<P, TPW, _Float16, true>(xt, (const _Float16 *)p.x, tokw, p.n_tokens, p.d, ebase);
+        } else {
+            if (p.x_dtype == RQAE_X_BF16) load_tile<P, TPW, uint16_t, false>(xt, (const uint16_t *)p.x, tokw, p.n_tokens, p.d, ebase);
+            else if (p.x_dtype == RQAE_X_F32) load_tile<P, TPW, float, false>(xt, (const float *)p.x, tokw, p.n_tokens, p.d, ebase);
+            else load_tile<P, TPW, _Float16, false>(xt, (const _Float16 *)p.x, tokw, p.n_tokens, p.d, ebase);
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) r2[i][pr] = (f2){xt[i][2 * pr], xt[i][2 * pr + 1]};
+    }
+    // One pass over this wave's registers.  DO_OUT: apply a level (lin_out, r -= y, out += y).
+    // DO_IN: project onto the next level (lin_in partials -> 64-lane tree -> LDS).
+    // FIRST: the reconstruction starts as 0 + y (rqae/model.py:201,224) -- no zeroed registers kept.
+    auto pass = [&](auto do_out_t, auto do_in_t, auto first_t) {
+        constexpr bool DO_OUT = decltype(do_out_t)::value, DO_IN = decltype(do_in_t)::value;
+        constexpr bool FIRST = decltype(first_t)::value;
+        const f4 *wl = reinterpret_cast<const f4 *>(wts) + (size_t)slice * P * QI * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f2 cv2[2][C];
+            if constexpr (DO_OUT) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        // wave-uniform values: keep them in SGPR pairs, not in 20 VGPRs
+                        const f2 v = *reinterpret_cast<const f2 *>(cvs + k * TG + half * TPW + 4 * g + 2 * pr);
+                        cv2[pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
+                    }
+            }
+            f2 acc2[2][C];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int j = 0; j < C; ++j) acc2[pr][j] = splat2(0.0f);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                float w[QI * 4];
+#pragma unroll
+                for (int qd = 0; qd < QI; ++qd) {
+                    const f4 v = wl[(i * QI + qd) * 64];
+                    w[4 * qd] = v.x; w[4 * qd + 1] = v.y; w[4 * qd + 2] = v.z; w[4 * qd + 3] = v.w;
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    f2 &rr = r2[i][2 * g + pr];
+                    if constexpr (DO_OUT) {
+                        f2 y = splat2(0.0f);
+#pragma unroll
+                        for (int k = 0; k < C; ++k) y = fma2(cv2[pr][k], splat2(w[k]), y);
+                        y = y + splat2(w[C]);
+                        rr = rr - y;
+                        if constexpr (RECON) {
+                            if constexpr (FIRST) out2[i][2 * g + pr] = splat2(0.0f) + y;
+                            else out2[i][2 * g + pr] = out2[i][2 * g + pr] + y;
+                        }
+                    }
+                    if constexpr (DO_IN) {
+#pragma unroll
+                        for (int j = 0; j < C; ++j) acc2[pr][j] = fma2(rr, splat2(w[C + 1 + j]), acc2[pr][j]);
+                    }
+                }
+                // keep the schedule per element step: hoisting many steps' weight reads costs spills
+                if constexpr (RECON) { if (i & 1) __builtin_amdgcn_sched_barrier(0); }
+            }
+            if constexpr (DO_IN) {
+                float vals[4 * C];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int j = 0; j < C; ++j) {
+                        vals[(2 * pr) * C + j] = acc2[pr][j].x;
+                        vals[(2 * pr + 1) * C + j] = acc2[pr][j].y;
+                    }
+                float fin[1];
+                ReduceScatter<4 * C, 0, 1>::run(vals, fin, lane);
+                const int v0 = rs_value_of_lane(lane);
+                if (v0 < 4 * C) part[(slice * TG + half * TPW + 4 * g) * C + v0] = fin[0];
+            }
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+
+    // The quantise phase of level l (after the barrier that publishes `part`).
+    auto quantise = [&](int l, float bin_own) {
+        float q_own = 0.0f;
+        if (act) {
+            const float *ps = part + tl_q * C + jj;
+            const float s01 = ps[0] + ps[TG * C];
+            const float s23 = ps[2 * TG * C] + ps[3 * TG * C];
+            q_own = (s01 + s23) + bin_own;
+        }
+        float qk[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) qk[k] = __shfl(q_own, (lane / JW) * JW + k, 64);
+        const float nrm = aten_norm2<C>(qk, C);
+        const float xn_own = q_own / nrm;
+        f2 xs2[C];  // wave-uniform unit vectors of the wave's two tokens
+#pragma unroll
+        for (int k = 0; k < C; ++k) xs2[k] = (f2){lane_bcast(xn_own, k), lane_bcast(xn_own, JW + k)};
+
+        float best[TQ] = {-INFINITY, -INFINITY};
+        int bidx[TQ] = {0, 0};
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int row_base = ch * p.kch;
+            const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
+            if (ch > 0) {
+                __syncthreads();
+                stage_floats(cbl, p.cb + ((size_t)(shared_cb ? 0 : l) * p.K + row_base) * C, rows * C);
+                __syncthreads();
+            }
+#pragma unroll 4
+            for (int r0 = 0; r0 < rows; r0 += 64) {
+                const int row = r0 + lane;
+                const bool in = row < rows;
+                float cbv[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) cbv[k] = cbl[(in ? row : 0) * C + k];
+                f2 s = splat2(0.0f);
+#pragma unroll
+                for (int k = 0; k < C; ++k) s = fma2(xs2[k], splat2(cbv[k]), s);
+                if (in && s.x > best[0]) { best[0] = s.x; bidx[0] = row_base + row; }
+                if (in && s.y > best[1]) { best[1] = s.y; bidx[1] = row_base + row; }
+            }
+        }
+        // wave-wide first maximum per token: max by reduce-scatter, then the lowest row among its holders
+        float mx[1];
+        ReduceScatter<TQ, 0, 1, 1>::run(best, mx, lane);
+        int win[TQ];
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            const float m = lane_bcast(mx[0], t << 5);  // lanes with bit5 == t hold token t's maximum
+            const unsigned long long tie = __ballot(best[t] == m);
+            if (__popcll(tie) != 1) {  // duplicate codebook rows (or no ordered maximum: NaN): lowest index
+                int cand = best[t] == m ? bidx[t] : 0x7fffffff;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const int o = __shfl_xor(cand, off, 64);
+                    cand = o < cand ? o : cand;
+                }
+                win[t] = __builtin_amdgcn_readfirstlane(cand);
+                if (tie == 0ull) win[t] = 0;       // every similarity is NaN: argmax returns 0
+            } else {
+                win[t] = __builtin_amdgcn_readlane(bidx[t], __builtin_ctzll(tie));
+            }
+        }
+        if (act) {
+            const int mine = tq == 1 ? win[1] : win[0];
+            const float rowv = nchunk == 1 ? cbl[mine * C + jj]
+                                           : p.cb[((size_t)(shared_cb ? 0 : l) * p.K + mine) * C + jj];
+            const float diff = rowv - q_own;                  // straight-through value (model.py:218-220)
+            cvs[jj * TG + tl_q] = q_own + diff;
+            const long long tok = tok0 + tl_q;
+            if (jj == 0 && tok < p.n_tokens) p.idx[tok * p.levels + l] = mine;
+        }
+    };
+
+    // ---- level 0 projection
+    float bin_own = act ? p.b_in[jj] : 0.0f;
+    __syncthreads();                                      // record 0 + codebook landed
+    pass(F{}, T{}, F{});
+    __syncthreads();                                      // `part` published, wts free
+    if (!(p.ablate & 1)) issue_dma(1);
+    if (!(p.ablate & 2)) quantise(0, bin_own);
+    __syncthreads();                                      // cvs published, record 1 landed (vmcnt(0))
+
+    if (p.levels > 1) {                                   // level 0 applied, level 1 projected
+        bin_own = act ? p.b_in[C + jj] : 0.0f;
+        pass(T{}, T{}, T{});
+        if (!stage_once) {
+            const int rows = p.kch < p.K ? p.kch : p.K;
+            stage_floats(cbl, p.cb + (size_t)(shared_cb ? 0 : 1) * p.K * C, rows * C);
+        }
+        __syncthreads();
+        if (!(p.ablate & 1)) issue_dma(2);
+        if (!(p.ablate & 2)) quantise(1, bin_own);
+        __syncthreads();
+    }
+    for (int l = 1; l + 1 < p.levels; ++l) {
+        bin_own = act ? p.b_in[(l + 1) * C + jj] : 0.0f;
+        if (!(p.ablate & 4)) pass(T{}, T{}, F{});         // apply level l, project onto level l+1
+        if (!stage_once) {
+            const int rows = p.kch < p.K ? p.kch : p.K;
+            stage_floats(cbl, p.cb + (size_t)(shared_cb ? 0 : l + 1) * p.K * C, rows * C);
+        }
+        __syncthreads();
+        if (!(p.ablate & 1)) issue_dma(l + 2);
+        if (!(p.ablate & 2)) quantise(l + 1, bin_own);
+        __syncthreads();
+    }
+    if (p.levels > 1) pass(T{}, F{}, F{});                // apply the last level
+    else pass(T{}, F{}, T{});
+
+    if constexpr (RECON) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const long long tok = tokw + t;
+            float *op = p.q_out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d + ebase;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const float v = (t & 1) ? out2[i][t >> 1].y : out2[i][t >> 1].x;
+                if (full_tile) op[64 * i] = v;
+                else if (tok < p.n_tokens && ebase + 64 * i < p.d) op[64 * i] = v;
+            }
+        }
+    }
+}
+
+template <int P, int C>
+int launch_encode_lds(const EncParams &p, hipStream_t stream)
+{
+    constexpr int TG = 16;
+    constexpr int QI = (2 * C + 1 + 3) / 4;
+    EncParams q = p;
+    const size_t fixed = sizeof(float) * ((size_t)NSLICE * P * QI * 256 + NSLICE * TG * C + ((TG * C + 3) & ~3));
+    const size_t cb_budget = 160 * 1024 - fixed - 1024;
+    int kch = (int)(cb_budget / (sizeof(float) * p.c));
+    kch = (kch / 64) * 64;
+    if (kch < 64) return fail("encode: no LDS left for the codebook");
+    if (kch >= p.K) kch = ((p.K + 63) / 64) * 64;
+    q.kch = kch;
+    {
+        const char *ab = getenv("RQAE_HIP_ABLATE");
+        q.ablate = ab ? atoi(ab) : 0;
+    }
+    const int rows = kch < p.K ? kch : p.K;
+    const size_t lds = fixed + sizeof(float) * (size_t)rows * p.c;
+    const long long nblk = (p.n_tokens + TG - 1) / TG;
+    if (nblk > 0x7fffffffLL) return fail("encode: too many tokens for one launch");
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, stream, q);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true>);
+    return go(rqae_encode_lds_kernel<P, C, false>);
+}
+
 template <int P, int C, int TPW, int NH, bool GEN>
 int launch_encode(const EncParams &p, hipStream_t stream)
 {
@@ -514,7 +914,7 @@ int launch_encode(const EncParams &p, hipStream_t stream)
     return go(rqae_encode_kernel<P, C, TPW, NH, false, GEN>);
 }
 
-enum Variant { V_AUTO = 0, V_A = 1, V_B = 2, V_GEN = 3 };
+enum Variant { V_AUTO = 0, V_A = 1, V_B = 2, V_GEN = 3, V_F = 4 };
 
 Variant env_variant()
 {
@@ -523,6 +923,7 @@ Variant env_variant()
     if (!strcmp(s, "A")) return V_A;
     if (!strcmp(s, "B")) return V_B;
     if (!strcmp(s, "GEN")) return V_GEN;
+    if (!strcmp(s, "F")) return V_F;
     return V_AUTO;
 }
 
@@ -535,6 +936,17 @@ const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream
         if (p) *rc = launch_encode<__VA_ARGS__>(*p, stream); \
         return name;                                    \
     } while (0)
+#define RUNF(name, ...)                                       \
+    do {                                                      \
+        if (p) *rc = launch_encode_lds<__VA_ARGS__>(*p, stream); \
+        return name;                                          \
+    } while (0)
+    if (v == V_AUTO || v == V_F) {
+        if (P == 9 && c == 5) RUNF("encode_lds<P=9,C=5> 8 waves x 8 tokens, LDS-staged weights, pk-f32", 9, 5);
+        if (P == 9 && c == 4) RUNF("encode_lds<P=9,C=4> 8 waves x 8 tokens, LDS-staged weights, pk-f32", 9, 4);
+        if (P == 1 && c == 4) RUNF("encode_lds<P=1,C=4> 8 waves x 8 tokens, LDS-staged weights, pk-f32", 1, 4);
+    }
+#undef RUNF
     if (v != V_GEN) {
         if (P == 9 && c == 5) {
             if (v == V_B) RUN("encode<P=9,C=5,TPW=8,NH=2> 8 waves, 16 tokens/WG", 9, 5, 8, 2, false);
@@ -713,7 +1125,7 @@ int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t
         if (P == 9 && c == 5) return launch_decode<9, 5, 16, false>(p, from_idx, stream);
         if (P == 9 && c == 4) return launch_decode<9, 4, 16, false>(p, from_idx, stream);
         if (P == 1 && c == 4) return launch_decode<1, 4, 16, false>(p, from_idx, stream);
-        if (P == 14 && c == 13) return launch_decode<14, 13, 8, false>(p, from_idx, stream);
+        if (P == 14 && c == 13) return launch_decode<14, 13, 4, false>(p, from_idx, stream);
     }
     if (P <= 8) return launch_decode<8, 16, 4, true>(p, from_idx, stream);
     return launch_decode<32, 16, 4, true>(p, from_idx, stream);
@@ -721,7 +1133,7 @@ int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t
 
 struct PackedView {
     const Header *hdr;
-    const float *w_in, *w_out, *b_out, *b_in, *cb;
+    const float *w_in, *w_out, *b_out, *b_in, *cb, *rec_p;
     int dp;
 };
 
@@ -736,6 +1148,7 @@ PackedView view_of(const void *packed, int d, int c, int K, int L)
     v.b_out = reinterpret_cast<const float *>(b + lo.b_out);
     v.b_in = reinterpret_cast<const float *>(b + lo.b_in);
     v.cb = reinterpret_cast<const float *>(b + lo.cb);
+    v.rec_p = reinterpret_cast<const float *>(b + lo.rec_p);
     v.dp = lo.dp;
     return v;
 }
@@ -801,6 +1214,9 @@ int rqae_hip_pack(void *packed, int d, int c, int K, int L, const float *w_in, c
                        reinterpret_cast<float *>(b + lo.w_in), reinterpret_cast<float *>(b + lo.w_out),
                        reinterpret_cast<float *>(b + lo.b_out), w_in, w_out, b_out);
     HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(pack_records_kernel, dim3(2048), dim3(256), 0, s, h, lo.qi,
+                       reinterpret_cast<float *>(b + lo.rec_p), w_in, w_out, b_out);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b + lo.b_in, b_in, sizeof(float) * (size_t)L * c, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(b + lo.cb, codebook, sizeof(float) * (size_t)L * K * c, hipMemcpyDeviceToDevice, s));
     return 0;
@@ -819,6 +1235,7 @@ int rqae_hip_encode(const void *packed, int d, int c, int K, int L, const void *
     EncParams p;
     memset(&p, 0, sizeof(p));
     p.w_in = v.w_in; p.w_out = v.w_out; p.b_out = v.b_out; p.b_in = v.b_in; p.cb = v.cb; p.hdr = v.hdr;
+    p.rec_p = v.rec_p;
     p.x = x; p.q_out = q_out; p.idx = reinterpret_cast<long long *>(indices);
     p.n_tokens = n_tokens; p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.levels = levels; p.x_dtype = x_dtype;
     int rc = 0;

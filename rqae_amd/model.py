@@ -204,6 +204,7 @@ class RQAE(nn.Module):
             return
         cb = self.codebook.data
         self.codebook.data.copy_(cb / cb.norm(dim=-1, keepdim=True))
+        self._packed = None  # .data writes do not bump the parameter's version counter
 
     # -------------------------------------------------- cached metadata (not hot)
     @property

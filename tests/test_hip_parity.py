@@ -119,7 +119,11 @@ def test_generic_shape_free_codebook():
     # decode afterwards uses codebook[0] of the drifted parameter (model.py:234)
     with torch.inference_mode():
         dec = m.decode(torch.from_numpy(idx).to(DEV).view(1, meta["n"], -1))
-    assert np.array_equal(dec.cpu().numpy()[0][g["rows"]], g["dec_rows"])
+    dec = dec.cpu().numpy()[0]
+    # the renormalised rows are produced by torch on this device, so they (and the decode that
+    # reads them) match the CPU-captured fixture to rounding, and the oracle on the same rows exactly
+    assert rel_err(dec[g["rows"]], g["dec_rows"]) < RTOL
+    assert np.array_equal(dec, oracle.decode(idx, dict(w, codebook=m.codebook.detach().cpu().numpy())))
 
 
 def test_large_codebook_chunks_through_lds():

@@ -28,7 +28,7 @@ def test_packed_bytes_and_shape_limits():
     assert _native.lib().rqae_hip_packed_bytes(9000, 5, 10, 1) == 0     # d > 8192
     assert _native.lib().rqae_hip_packed_bytes(256, 17, 10, 1) == 0     # c > 16
     assert b"unsupported" in _native.lib().rqae_hip_last_error()
-    assert "TPW=16" in _native.kernel_info(2304, 5, 1024, 8)
+    assert "P=9,C=5" in _native.kernel_info(2304, 5, 1024, 8)
     assert "generic" in _native.kernel_info(512, 6, 300, 5)
 
 

@@ -54,25 +54,24 @@ def synth_batch(n_tokens, device, seed):
 
 def cpu_baseline(w, target_seconds=12.0):
     """The CPU oracle (a port of the reference's math, pinned to its golden vectors) timed on
-    this host's cores on a bounded sample of the same workload."""
+    this host's cores on a bounded sample of the same workload (~10-15 s of CPU work)."""
     import oracle
     from rqae_amd import synth
 
     threads = oracle.max_threads()
-    probe = synth.round_to_bf16(synth.activations(1000, 2048, CFG["dim"]))
-    oracle.forward(probe[:256], w, threads=threads)  # warm
-    t0 = time.perf_counter()
-    oracle.forward(probe, w, threads=threads)
-    rate = 2048 / (time.perf_counter() - t0)
-    n = int(min(262144, max(4096, rate * target_seconds)))
-    n -= n % 1024
+    n = 32768
     x = synth.round_to_bf16(synth.activations(1001, n, CFG["dim"]))
-    t0 = time.perf_counter()
-    oracle.forward(x, w, threads=threads)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"{n} tokens of the same workload (bf16-rounded synthetic rows, d=2304 K=1024 depth=8), "
-                      f"oracle/rqae_oracle.c with {threads} OpenMP threads, {dt:.1f} s"}
+    oracle.forward(x[:1024], w, threads=threads)  # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle.forward(x, w, threads=threads)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or reps >= 200:
+            break
+    return {"value": n * reps / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x {n} tokens of the same workload (bf16-rounded synthetic rows, d=2304 K=1024 depth=8, "
+                      f"codes + reconstruction), oracle/rqae_oracle.c with {threads} OpenMP threads, {dt:.1f} s"}
 
 
 def main():
@@ -110,33 +109,29 @@ def main():
     x = synth_batch(args.tokens, device, seed=1000 + rank).view(1, args.tokens, CFG["dim"])
     fn = model.encode if args.codes_only else model.forward
 
+    from rqae_amd import sharding
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.inference_mode():
-        for _ in range(args.warmup):
-            fn(x)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        barrier()
-        t0 = time.perf_counter()
-        for a, b in evs:
-            a.record()          # same stream the kernel is launched on (torch's current stream)
-            fn(x)
-            b.record()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    evs = []
 
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def step():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()              # same stream the kernel is launched on (torch's current stream)
+        fn(x)
+        b.record()
+        evs.append((a, b))
+
+    with torch.inference_mode():
+        elapsed = sharding.timed_steps(step, args.steps, args.warmup, barrier)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[args.warmup:]]))
+    elapsed = sharding.max_over_ranks(elapsed, dist, device)
 
     if rank == 0:
-        total_tokens = args.tokens * world * args.steps
-        value = total_tokens / elapsed
+        value = sharding.aggregate_throughput(args.tokens, world, args.steps, elapsed)
         bytes_tok = (D * 2 + L * 8) if args.codes_only else BYTES_PER_TOKEN
         tok_per_s_kernel = args.tokens / (kern_ms * 1e-3)
         tflops = tok_per_s_kernel * FLOPS_PER_TOKEN / 1e12

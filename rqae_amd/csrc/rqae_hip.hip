@@ -31,7 +31,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "../../include/rqae_hip.h"
 
@@ -63,6 +65,23 @@ int fail(const char *fmt, ...)
     } while (0)
 
 // ---------------------------------------------------------------- packed block
+// Host-side note of what rqae_hip_pack was told about each block it built (the header itself
+// lives in device memory and is only read by kernels).  Unknown pointer => assume per-level codebooks.
+std::mutex g_reg_mutex;
+std::unordered_map<const void *, int> g_shared_cb;
+
+void note_packed(const void *packed, int shared)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    g_shared_cb[packed] = shared;
+}
+bool packed_has_shared_codebook(const void *packed)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    auto it = g_shared_cb.find(packed);
+    return it != g_shared_cb.end() && it->second != 0;
+}
+
 struct Header {
     int magic, d, c, K, L, dp, shared_cb, pad;
 };
@@ -591,7 +610,12 @@ __device__ __forceinline__ void dma_1k(const float *g_lane, float *lds_piece)
                                      (__attribute__((address_space(3))) void *)lds_piece, 16, 0, 0);
 }
 
-template <int P, int C, bool RECON>
+// MFMA: lin_out and the cosine contraction run on the matrix pipe as v_mfma_f32_4x4x1_16b_f32 with
+// the A operand broadcast from block 0 (cbsz=4): D[lane][i] = A[lane i] * B[lane] + C[lane][i], i.e.
+// lane = element (or codebook row), the four accumulator registers = four tokens.  K = 1 per
+// instruction, so a chain of c instructions is the k-ordered fmaf chain of the contract, bit for bit
+// (checked on hardware by the parity tests), with no padding of c.
+template <int P, int C, bool RECON, bool MFMA>
 __global__ void __launch_bounds__(512, 2)
 rqae_encode_lds_kernel(const EncParams p)
 {
@@ -665,37 +689,65 @@ rqae_encode_lds_kernel(const EncParams p)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             f2 cv2[2][C];
+            float a_cv[C];   // MFMA A operands: lane i (0..3) holds the value of token 4g+i
             if constexpr (DO_OUT) {
+                if constexpr (MFMA) {
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr)
+                    for (int k = 0; k < C; ++k) a_cv[k] = cvs[k * TG + half * TPW + 4 * g + (lane & 3)];
+                } else {
 #pragma unroll
-                    for (int k = 0; k < C; ++k) {
-                        // wave-uniform values: keep them in SGPR pairs, not in 20 VGPRs
-                        const f2 v = *reinterpret_cast<const f2 *>(cvs + k * TG + half * TPW + 4 * g + 2 * pr);
-                        cv2[pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
-                    }
+                    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                        for (int k = 0; k < C; ++k) {
+                            // wave-uniform values: keep them in SGPR pairs, not in 20 VGPRs
+                            const f2 v = *reinterpret_cast<const f2 *>(cvs + k * TG + half * TPW + 4 * g + 2 * pr);
+                            cv2[pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
+                        }
+                }
             }
             f2 acc2[2][C];
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
                 for (int j = 0; j < C; ++j) acc2[pr][j] = splat2(0.0f);
+            // weights of element step i+1 are fetched from LDS while step i computes
+            f4 wq[2][QI];
+#pragma unroll
+            for (int qd = 0; qd < QI; ++qd) wq[0][qd] = wl[qd * 64];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
+                if (i + 1 < P) {
+#pragma unroll
+                    for (int qd = 0; qd < QI; ++qd) wq[(i + 1) & 1][qd] = wl[((i + 1) * QI + qd) * 64];
+                }
                 float w[QI * 4];
 #pragma unroll
                 for (int qd = 0; qd < QI; ++qd) {
-                    const f4 v = wl[(i * QI + qd) * 64];
+                    const f4 v = wq[i & 1][qd];
                     w[4 * qd] = v.x; w[4 * qd + 1] = v.y; w[4 * qd + 2] = v.z; w[4 * qd + 3] = v.w;
+                }
+                f2 ym[2];
+                if constexpr (DO_OUT && MFMA) {
+                    f4 y4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < C; ++k) y4 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cv[k], w[k], y4, 4, 0, 0);
+                    y4 = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, w[C], y4, 4, 0, 0);   // + bias, one rounding
+                    ym[0] = (f2){y4.x, y4.y};
+                    ym[1] = (f2){y4.z, y4.w};
                 }
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     f2 &rr = r2[i][2 * g + pr];
                     if constexpr (DO_OUT) {
-                        f2 y = splat2(0.0f);
+                        f2 y;
+                        if constexpr (MFMA) {
+                            y = ym[pr];
+                        } else {
+                            y = splat2(0.0f);
 #pragma unroll
-                        for (int k = 0; k < C; ++k) y = fma2(cv2[pr][k], splat2(w[k]), y);
-                        y = y + splat2(w[C]);
+                            for (int k = 0; k < C; ++k) y = fma2(cv2[pr][k], splat2(w[k]), y);
+                            y = y + splat2(w[C]);
+                        }
                         rr = rr - y;
                         if constexpr (RECON) {
                             if constexpr (FIRST) out2[i][2 * g + pr] = splat2(0.0f) + y;
@@ -707,8 +759,6 @@ rqae_encode_lds_kernel(const EncParams p)
                         for (int j = 0; j < C; ++j) acc2[pr][j] = fma2(rr, splat2(w[C + 1 + j]), acc2[pr][j]);
                     }
                 }
-                // keep the schedule per element step: hoisting many steps' weight reads costs spills
-                if constexpr (RECON) { if (i & 1) __builtin_amdgcn_sched_barrier(0); }
             }
             if constexpr (DO_IN) {
                 float vals[4 * C];
@@ -743,12 +793,18 @@ rqae_encode_lds_kernel(const EncParams p)
         for (int k = 0; k < C; ++k) qk[k] = __shfl(q_own, (lane / JW) * JW + k, 64);
         const float nrm = aten_norm2<C>(qk, C);
         const float xn_own = q_own / nrm;
-        f2 xs2[C];  // wave-uniform unit vectors of the wave's two tokens
-#pragma unroll
-        for (int k = 0; k < C; ++k) xs2[k] = (f2){lane_bcast(xn_own, k), lane_bcast(xn_own, JW + k)};
-
         float best[TQ] = {-INFINITY, -INFINITY};
         int bidx[TQ] = {0, 0};
+        f2 xs2[C];   // VALU path: wave-uniform unit vectors of the wave's two tokens
+        float xa[C]; // MFMA path: A operands, lane 0 / lane 1 = token 0 / token 1
+        if constexpr (MFMA) {
+            const float xz = act ? xn_own : 0.0f;
+#pragma unroll
+            for (int k = 0; k < C; ++k) xa[k] = __shfl(xz, (lane & 3) * JW + k, 64);
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) xs2[k] = (f2){lane_bcast(xn_own, k), lane_bcast(xn_own, JW + k)};
+        }
         for (int ch = 0; ch < nchunk; ++ch) {
             const int row_base = ch * p.kch;
             const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
@@ -764,11 +820,20 @@ rqae_encode_lds_kernel(const EncParams p)
                 float cbv[C];
 #pragma unroll
                 for (int k = 0; k < C; ++k) cbv[k] = cbl[(in ? row : 0) * C + k];
-                f2 s = splat2(0.0f);
+                float s0, s1;
+                if constexpr (MFMA) {
+                    f4 s4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int k = 0; k < C; ++k) s = fma2(xs2[k], splat2(cbv[k]), s);
-                if (in && s.x > best[0]) { best[0] = s.x; bidx[0] = row_base + row; }
-                if (in && s.y > best[1]) { best[1] = s.y; bidx[1] = row_base + row; }
+                    for (int k = 0; k < C; ++k) s4 = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[k], cbv[k], s4, 4, 0, 0);
+                    s0 = s4.x; s1 = s4.y;
+                } else {
+                    f2 s = splat2(0.0f);
+#pragma unroll
+                    for (int k = 0; k < C; ++k) s = fma2(xs2[k], splat2(cbv[k]), s);
+                    s0 = s.x; s1 = s.y;
+                }
+                if (in && s0 > best[0]) { best[0] = s0; bidx[0] = row_base + row; }
+                if (in && s1 > best[1]) { best[1] = s1; bidx[1] = row_base + row; }
             }
         }
         // wave-wide first maximum per token: max by reduce-scatter, then the lowest row among its holders
@@ -854,8 +919,9 @@ rqae_encode_lds_kernel(const EncParams p)
     }
 }
 
+
 template <int P, int C>
-int launch_encode_lds(const EncParams &p, hipStream_t stream)
+int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
 {
     constexpr int TG = 16;
     constexpr int QI = (2 * C + 1 + 3) / 4;
@@ -883,8 +949,12 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream)
         HIP_TRY(hipGetLastError());
         return 0;
     };
-    if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true>);
-    return go(rqae_encode_lds_kernel<P, C, false>);
+    if (use_mfma) {
+        if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, true>);
+        return go(rqae_encode_lds_kernel<P, C, false, true>);
+    }
+    if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, false>);
+    return go(rqae_encode_lds_kernel<P, C, false, false>);
 }
 
 template <int P, int C, int TPW, int NH, bool GEN>
@@ -914,7 +984,7 @@ int launch_encode(const EncParams &p, hipStream_t stream)
     return go(rqae_encode_kernel<P, C, TPW, NH, false, GEN>);
 }
 
-enum Variant { V_AUTO = 0, V_A = 1, V_B = 2, V_GEN = 3, V_F = 4 };
+enum Variant { V_AUTO = 0, V_A = 1, V_B = 2, V_GEN = 3, V_M = 4 };
 
 Variant env_variant()
 {
@@ -923,14 +993,21 @@ Variant env_variant()
     if (!strcmp(s, "A")) return V_A;
     if (!strcmp(s, "B")) return V_B;
     if (!strcmp(s, "GEN")) return V_GEN;
-    if (!strcmp(s, "F")) return V_F;
+    if (!strcmp(s, "M")) return V_M;
     return V_AUTO;
 }
 
 // Which instantiation serves (P, c).  Returns a name; launches when p != nullptr.
-const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream, int *rc)
+const char *dispatch_encode(int P, int c, bool shared_cb, const EncParams *p, hipStream_t stream, int *rc)
 {
     const Variant v = env_variant();
+#ifdef RQAE_EXPERIMENT_ONLY_95   // compile-time experiments: one instantiation, fast rebuilds
+    {
+        if (p) *rc = launch_encode_lds<9, 5>(*p, stream, v == V_M);
+        (void)shared_cb; (void)v; (void)P; (void)c;
+        return "experiment";
+    }
+#else
 #define RUN(name, ...)                                  \
     do {                                                \
         if (p) *rc = launch_encode<__VA_ARGS__>(*p, stream); \
@@ -938,13 +1015,16 @@ const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream
     } while (0)
 #define RUNF(name, ...)                                       \
     do {                                                      \
-        if (p) *rc = launch_encode_lds<__VA_ARGS__>(*p, stream); \
+        if (p) *rc = launch_encode_lds<__VA_ARGS__>(*p, stream, v == V_M); \
         return name;                                          \
     } while (0)
-    if (v == V_AUTO || v == V_F) {
-        if (P == 9 && c == 5) RUNF("encode_lds<P=9,C=5> 8 waves x 8 tokens, LDS-staged weights, pk-f32", 9, 5);
-        if (P == 9 && c == 4) RUNF("encode_lds<P=9,C=4> 8 waves x 8 tokens, LDS-staged weights, pk-f32", 9, 4);
-        if (P == 1 && c == 4) RUNF("encode_lds<P=1,C=4> 8 waves x 8 tokens, LDS-staged weights, pk-f32", 1, 4);
+    // M = the arm that puts lin_out and the cosine contraction on the matrix pipe (v_mfma_f32_4x4x1_16b).
+    // Bit-identical output; measured 10-17 % slower than the packed-VALU arm on MI355X.
+    if (v == V_AUTO || v == V_M) {
+        const bool m = v == V_M;
+        if (P == 9 && c == 5) RUNF(m ? "encode_lds<P=9,C=5> MFMA 4x4x1 arm" : "encode_lds<P=9,C=5> 8 waves x 8 tokens, LDS-DMA weights, fused pass in packed fp32", 9, 5);
+        if (P == 9 && c == 4) RUNF(m ? "encode_lds<P=9,C=4> MFMA 4x4x1 arm" : "encode_lds<P=9,C=4> 8 waves x 8 tokens, LDS-DMA weights, fused pass in packed fp32", 9, 4);
+        if (P == 1 && c == 4) RUNF(m ? "encode_lds<P=1,C=4> MFMA 4x4x1 arm" : "encode_lds<P=1,C=4> 8 waves x 8 tokens, LDS-DMA weights, fused pass in packed fp32", 1, 4);
     }
 #undef RUNF
     if (v != V_GEN) {
@@ -959,6 +1039,7 @@ const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream
     if (P <= 8) RUN("encode<generic P<=8,C<=16,TPW=2>", 8, 16, 2, 1, true);
     RUN("encode<generic P<=32,C<=16,TPW=2>", 32, 16, 2, 1, true);
 #undef RUN
+#endif
 }
 
 // ---------------------------------------------------------------- quantize kernel
@@ -1121,6 +1202,9 @@ int launch_decode(const DecParams &p, bool from_idx, hipStream_t stream)
 
 int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t stream)
 {
+#ifdef RQAE_EXPERIMENT_ONLY_95
+    return fail("experiment build");
+#else
     if (env_variant() != V_GEN) {
         if (P == 9 && c == 5) return launch_decode<9, 5, 16, false>(p, from_idx, stream);
         if (P == 9 && c == 4) return launch_decode<9, 4, 16, false>(p, from_idx, stream);
@@ -1129,6 +1213,7 @@ int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t
     }
     if (P <= 8) return launch_decode<8, 16, 4, true>(p, from_idx, stream);
     return launch_decode<32, 16, 4, true>(p, from_idx, stream);
+#endif
 }
 
 struct PackedView {
@@ -1219,6 +1304,7 @@ int rqae_hip_pack(void *packed, int d, int c, int K, int L, const float *w_in, c
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b + lo.b_in, b_in, sizeof(float) * (size_t)L * c, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(b + lo.cb, codebook, sizeof(float) * (size_t)L * K * c, hipMemcpyDeviceToDevice, s));
+    note_packed(packed, codebook_shared ? 1 : 0);
     return 0;
 }
 
@@ -1239,7 +1325,7 @@ int rqae_hip_encode(const void *packed, int d, int c, int K, int L, const void *
     p.x = x; p.q_out = q_out; p.idx = reinterpret_cast<long long *>(indices);
     p.n_tokens = n_tokens; p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.levels = levels; p.x_dtype = x_dtype;
     int rc = 0;
-    dispatch_encode(v.dp / 256, c, &p, static_cast<hipStream_t>(stream), &rc);
+    dispatch_encode(v.dp / 256, c, packed_has_shared_codebook(packed), &p, static_cast<hipStream_t>(stream), &rc);
     return rc;
 }
 
@@ -1248,7 +1334,7 @@ int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen)
     if (!shape_ok(d, c, K, L)) return fail("kernel_info: unsupported shape");
     if (!buf || !buflen) return fail("kernel_info: null buffer");
     int rc = 0;
-    const char *name = dispatch_encode(((d + 255) / 256), c, nullptr, nullptr, &rc);
+    const char *name = dispatch_encode(((d + 255) / 256), c, true, nullptr, nullptr, &rc);
     snprintf(buf, buflen, "%s", name);
     return 0;
 }

@@ -52,7 +52,7 @@ def test_forward_golden_and_oracle(name):
     assert np.array_equal(q, q_o)
 
 
-@pytest.mark.parametrize("variant", ["A", "B", "GEN"])
+@pytest.mark.parametrize("variant", ["A", "B", "GEN", "M"])
 def test_kernel_variants_agree(variant, monkeypatch):
     monkeypatch.setenv("RQAE_HIP_VARIANT", variant)
     cfg = synth.CONFIGS["C2"]

@@ -751,7 +751,8 @@ rqae_encode_lds_kernel(const EncParams p)
                         rr = rr - y;
                         if constexpr (RECON) {
                             if constexpr (FIRST) out2[i][2 * g + pr] = splat2(0.0f) + y;
-                            else out2[i][2 * g + pr] = out2[i][2 * g + pr] + y;
+                            else  // one opaque instruction: written as C++ the allocator needs ~60 more VGPRs and spills
+                                asm("v_pk_add_f32 %0, %0, %1" : "+v"(out2[i][2 * g + pr]) : "v"(y));
                         }
                     }
                     if constexpr (DO_IN) {

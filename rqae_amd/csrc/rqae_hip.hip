@@ -603,11 +603,71 @@ __device__ __forceinline__ float lane_bcast_first(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
-// 1 KiB per wave-instruction, global -> LDS without touching VGPRs; lds_piece is wave-uniform
-__device__ __forceinline__ void dma_1k(const float *g_lane, float *lds_piece)
+// Codebook rows in LDS for the LDS kernel: columns 0..3 of every row as one float4 (conflict-free
+// ds_read_b128, 16-byte lane stride), the remaining C-4 columns in a second array behind them.
+constexpr int cb_lds_floats(int C, int rows) { return rows * (C <= 4 ? 4 : 4 + (C - 4)); }
+template <int C>
+__device__ __forceinline__ void stage_rows(float *dst, const float *src, int rows)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
-                                     (__attribute__((address_space(3))) void *)lds_piece, 16, 0, 0);
+    constexpr int CB = C > 4 ? C - 4 : 1;
+    float *tailp = dst + (size_t)rows * 4;
+    for (int u = threadIdx.x; u < rows * C; u += blockDim.x) {
+        const int r = u / C, k = u - r * C;
+        const float v = src[u];
+        if (k < 4) dst[r * 4 + k] = v;
+        else tailp[r * CB + (k - 4)] = v;
+    }
+    if constexpr (C < 4) {   // zero the unused columns (they are read as part of the float4)
+        for (int u = threadIdx.x; u < rows * (4 - C); u += blockDim.x) {
+            const int r = u / (4 - C), k = C + u % (4 - C);
+            dst[r * 4 + k] = 0.0f;
+        }
+    }
+}
+template <int C>
+__device__ __forceinline__ void load_row(float (&cbv)[C], const float *cbl_base, int row, int rows_staged)
+{
+    const float4 h = *reinterpret_cast<const float4 *>(cbl_base + row * 4);
+    const float hv[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+    for (int k = 0; k < C && k < 4; ++k) cbv[k] = hv[k];
+    if constexpr (C > 4) {
+        const float *tailp = cbl_base + (size_t)rows_staged * 4 + row * (C - 4);
+#pragma unroll
+        for (int k = 4; k < C; ++k) cbv[k] = tailp[k - 4];
+    }
+}
+template <int C>
+__device__ __forceinline__ float row_elem(const float *cbl_base, int row, int k, int rows_staged)
+{
+    if (C <= 4 || k < 4) return cbl_base[row * 4 + k];
+    return cbl_base[(size_t)rows_staged * 4 + row * (C - 4) + (k - 4)];
+}
+
+// NQ consecutive 1-KiB pieces by LDS-DMA with scalar addressing: global source = uniform base +
+// lane*16 (+1 KiB per piece as the immediate), LDS destination = M0 (+1 KiB per piece).  Written in
+// asm on purpose: after the builtin form hipcc puts s_waitcnt vmcnt(0) in front of the next ds_read,
+// which serialises the transfer with the quantise phase it is meant to hide behind (measured: the
+// builtin cost 0.4 ms per launch whether or not the quantise phase ran).  M0 is saved/restored; the
+// reader side waits with dma_wait_all() before the barrier that publishes the data.
+template <int NQ>
+__device__ __forceinline__ void dma_pieces(const float *g_uniform, unsigned lds_byte_addr, unsigned lane_byte_off)
+{
+    static_assert(NQ * 1024 <= 4096, "immediate offset range of global_load_lds");
+    unsigned keep;
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_byte_off), "s"(g_uniform), "s"(lds_byte_addr + qd * 1024), "i"(qd * 1024)
+                     : "memory");
+    }
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr_of(const float *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const float *)p;
 }
 
 // MFMA: lin_out and the cosine contraction run on the matrix pipe as v_mfma_f32_4x4x1_16b_f32 with
@@ -628,7 +688,7 @@ rqae_encode_lds_kernel(const EncParams p)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *wts = smem;                       // [slice][i][quad][lane][4]
-    float *part = wts + WFLOATS;             // [NSLICE][TG][C]
+    float *part = wts + WFLOATS;             // [TG][C][NSLICE]: the 4 slice partials of one (token, j) are contiguous
     float *cvs = part + NSLICE * TG * C;     // [C][TG]  (token pairs contiguous)
     float *cbl = cvs + ((TG * C + 3) & ~3);  // [kch][C]
 
@@ -649,15 +709,16 @@ rqae_encode_lds_kernel(const EncParams p)
     const int tl_q = wave * TQ + (tq < TQ ? tq : 0);
     const bool act = tq < TQ && jj < C;
 
+    const unsigned wts_addr = lds_addr_of(wts);
     auto issue_dma = [&](int pl) {           // the record of pass pl -> wts (all 8 waves share the work)
-        const float *src = p.rec_p + (size_t)pl * WFLOATS + lane * 4;
-        for (int pc = wave; pc < NPIECE; pc += NW) dma_1k(src + pc * 256, wts + pc * 256);
+        const float *src = p.rec_p + (size_t)pl * WFLOATS;   // uniform
+        for (int pc = wave; pc < NPIECE; pc += NW) dma_pieces<1>(src + pc * 256, wts_addr + pc * 1024, lane * 16);
     };
 
     issue_dma(0);
     {
         const int rows = p.kch < p.K ? p.kch : p.K;
-        stage_floats(cbl, p.cb, rows * C);
+        stage_rows<C>(cbl, p.cb, rows);
     }
 
     f2 r2[P][NPAIR];
@@ -773,7 +834,7 @@ rqae_encode_lds_kernel(const EncParams p)
                 float fin[1];
                 ReduceScatter<4 * C, 0, 1>::run(vals, fin, lane);
                 const int v0 = rs_value_of_lane(lane);
-                if (v0 < 4 * C) part[(slice * TG + half * TPW + 4 * g) * C + v0] = fin[0];
+                if (v0 < 4 * C) part[((half * TPW + 4 * g) * C + v0) * NSLICE + slice] = fin[0];
             }
         }
     };
@@ -784,9 +845,9 @@ rqae_encode_lds_kernel(const EncParams p)
     auto quantise = [&](int l, float bin_own) {
         float q_own = 0.0f;
         if (act) {
-            const float *ps = part + tl_q * C + jj;
-            const float s01 = ps[0] + ps[TG * C];
-            const float s23 = ps[2 * TG * C] + ps[3 * TG * C];
+            const f4 ps = *reinterpret_cast<const f4 *>(part + (tl_q * C + jj) * NSLICE);
+            const float s01 = ps.x + ps.y;
+            const float s23 = ps.z + ps.w;
             q_own = (s01 + s23) + bin_own;
         }
         float qk[C];
@@ -811,16 +872,13 @@ rqae_encode_lds_kernel(const EncParams p)
             const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
             if (ch > 0) {
                 __syncthreads();
-                stage_floats(cbl, p.cb + ((size_t)(shared_cb ? 0 : l) * p.K + row_base) * C, rows * C);
+                stage_rows<C>(cbl, p.cb + ((size_t)(shared_cb ? 0 : l) * p.K + row_base) * C, rows);
                 __syncthreads();
             }
-#pragma unroll 4
-            for (int r0 = 0; r0 < rows; r0 += 64) {
+            auto scan_block = [&](int r0, bool in) {
                 const int row = r0 + lane;
-                const bool in = row < rows;
                 float cbv[C];
-#pragma unroll
-                for (int k = 0; k < C; ++k) cbv[k] = cbl[(in ? row : 0) * C + k];
+                load_row<C>(cbv, cbl, in ? row : 0, rows);
                 float s0, s1;
                 if constexpr (MFMA) {
                     f4 s4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -835,7 +893,11 @@ rqae_encode_lds_kernel(const EncParams p)
                 }
                 if (in && s0 > best[0]) { best[0] = s0; bidx[0] = row_base + row; }
                 if (in && s1 > best[1]) { best[1] = s1; bidx[1] = row_base + row; }
-            }
+            };
+            const int full = rows & ~63;
+#pragma unroll 4
+            for (int r0 = 0; r0 < full; r0 += 64) scan_block(r0, true);
+            if (full < rows) scan_block(full, full + lane < rows);
         }
         // wave-wide first maximum per token: max by reduce-scatter, then the lowest row among its holders
         float mx[1];
@@ -860,7 +922,7 @@ rqae_encode_lds_kernel(const EncParams p)
         }
         if (act) {
             const int mine = tq == 1 ? win[1] : win[0];
-            const float rowv = nchunk == 1 ? cbl[mine * C + jj]
+            const float rowv = nchunk == 1 ? row_elem<C>(cbl, mine, jj, p.kch < p.K ? p.kch : p.K)
                                            : p.cb[((size_t)(shared_cb ? 0 : l) * p.K + mine) * C + jj];
             const float diff = rowv - q_own;                  // straight-through value (model.py:218-220)
             cvs[jj * TG + tl_q] = q_own + diff;
@@ -869,38 +931,48 @@ rqae_encode_lds_kernel(const EncParams p)
         }
     };
 
+    // lin_in bias of level l for this lane's (token, j).  It is loaded before the pass and pinned
+    // (land_bias) before the LDS-DMA is issued: a vmcnt wait on it placed later would also wait for
+    // the whole DMA and serialise it with the quantise phase.
+    auto bias_of = [&](int l) { return act ? p.b_in[l * C + jj] : 0.0f; };
+    auto land_bias = [&](float &b) { asm volatile("" : "+v"(b)); };
+    auto slot_end = [&]() { dma_wait_all(); __syncthreads(); };
+
     // ---- level 0 projection
-    float bin_own = act ? p.b_in[jj] : 0.0f;
-    __syncthreads();                                      // record 0 + codebook landed
+    float bin_own = bias_of(0);
+    slot_end();                                           // record 0 + codebook landed
     pass(F{}, T{}, F{});
+    land_bias(bin_own);
     __syncthreads();                                      // `part` published, wts free
     if (!(p.ablate & 1)) issue_dma(1);
     if (!(p.ablate & 2)) quantise(0, bin_own);
-    __syncthreads();                                      // cvs published, record 1 landed (vmcnt(0))
+    slot_end();                                           // cvs published, record 1 landed
 
     if (p.levels > 1) {                                   // level 0 applied, level 1 projected
-        bin_own = act ? p.b_in[C + jj] : 0.0f;
+        bin_own = bias_of(1);
         pass(T{}, T{}, T{});
         if (!stage_once) {
             const int rows = p.kch < p.K ? p.kch : p.K;
-            stage_floats(cbl, p.cb + (size_t)(shared_cb ? 0 : 1) * p.K * C, rows * C);
+            stage_rows<C>(cbl, p.cb + (size_t)(shared_cb ? 0 : 1) * p.K * C, rows);
         }
+        land_bias(bin_own);
         __syncthreads();
         if (!(p.ablate & 1)) issue_dma(2);
         if (!(p.ablate & 2)) quantise(1, bin_own);
-        __syncthreads();
+        slot_end();
     }
     for (int l = 1; l + 1 < p.levels; ++l) {
-        bin_own = act ? p.b_in[(l + 1) * C + jj] : 0.0f;
+        bin_own = bias_of(l + 1);
         if (!(p.ablate & 4)) pass(T{}, T{}, F{});         // apply level l, project onto level l+1
         if (!stage_once) {
             const int rows = p.kch < p.K ? p.kch : p.K;
-            stage_floats(cbl, p.cb + (size_t)(shared_cb ? 0 : l + 1) * p.K * C, rows * C);
+            stage_rows<C>(cbl, p.cb + (size_t)(shared_cb ? 0 : l + 1) * p.K * C, rows);
         }
+        land_bias(bin_own);
         __syncthreads();
         if (!(p.ablate & 1)) issue_dma(l + 2);
         if (!(p.ablate & 2)) quantise(l + 1, bin_own);
-        __syncthreads();
+        slot_end();
     }
     if (p.levels > 1) pass(T{}, F{}, F{});                // apply the last level
     else pass(T{}, F{}, T{});
@@ -929,7 +1001,7 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
     EncParams q = p;
     const size_t fixed = sizeof(float) * ((size_t)NSLICE * P * QI * 256 + NSLICE * TG * C + ((TG * C + 3) & ~3));
     const size_t cb_budget = 160 * 1024 - fixed - 1024;
-    int kch = (int)(cb_budget / (sizeof(float) * p.c));
+    int kch = (int)(cb_budget / (sizeof(float) * cb_lds_floats(C, 1)));
     kch = (kch / 64) * 64;
     if (kch < 64) return fail("encode: no LDS left for the codebook");
     if (kch >= p.K) kch = ((p.K + 63) / 64) * 64;
@@ -939,7 +1011,7 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
         q.ablate = ab ? atoi(ab) : 0;
     }
     const int rows = kch < p.K ? kch : p.K;
-    const size_t lds = fixed + sizeof(float) * (size_t)rows * p.c;
+    const size_t lds = fixed + sizeof(float) * (size_t)cb_lds_floats(C, rows);
     const long long nblk = (p.n_tokens + TG - 1) / TG;
     if (nblk > 0x7fffffffLL) return fail("encode: too many tokens for one launch");
     auto go = [&](auto kern) -> int {

@@ -814,6 +814,15 @@ rqae_encode_lds_kernel(const EncParams p)
                             if constexpr (FIRST) out2[i][2 * g + pr] = splat2(0.0f) + y;
                             else  // one opaque instruction: written as C++ the allocator needs ~60 more VGPRs and spills
                                 asm("v_pk_add_f32 %0, %0, %1" : "+v"(out2[i][2 * g + pr]) : "v"(y));
+                            if constexpr (!DO_IN) {
+                                // last level: this element pair is final -- store it now, under the rest of the pass
+                                if (full_tile) {
+                                    const int t0 = 4 * g + 2 * pr;
+                                    float *o0 = p.q_out + (size_t)(tokw + t0) * p.d;
+                                    o0[ebase + 64 * i] = out2[i][2 * g + pr].x;
+                                    o0[(size_t)p.d + ebase + 64 * i] = out2[i][2 * g + pr].y;
+                                }
+                            }
                         }
                     }
                     if constexpr (DO_IN) {
@@ -978,20 +987,20 @@ rqae_encode_lds_kernel(const EncParams p)
     else pass(T{}, F{}, T{});
 
     if constexpr (RECON) {
+        if (!full_tile) {   // ragged tile: predicated stores after the loop (full tiles stored inside the last pass)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const long long tok = tokw + t;
-            float *op = p.q_out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d + ebase;
+            for (int t = 0; t < TPW; ++t) {
+                const long long tok = tokw + t;
+                float *op = p.q_out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d + ebase;
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const float v = (t & 1) ? out2[i][t >> 1].y : out2[i][t >> 1].x;
-                if (full_tile) op[64 * i] = v;
-                else if (tok < p.n_tokens && ebase + 64 * i < p.d) op[64 * i] = v;
+                for (int i = 0; i < P; ++i) {
+                    const float v = (t & 1) ? out2[i][t >> 1].y : out2[i][t >> 1].x;
+                    if (tok < p.n_tokens && ebase + 64 * i < p.d) op[64 * i] = v;
+                }
             }
         }
     }
 }
-
 
 template <int P, int C>
 int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)

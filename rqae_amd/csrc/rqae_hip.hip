@@ -610,12 +610,25 @@ template <int C>
 __device__ __forceinline__ void stage_rows(float *dst, const float *src, int rows)
 {
     constexpr int CB = C > 4 ? C - 4 : 1;
+    constexpr int BATCH = 8;   // independent loads in flight per thread: one L2 latency per batch, not per float
     float *tailp = dst + (size_t)rows * 4;
-    for (int u = threadIdx.x; u < rows * C; u += blockDim.x) {
-        const int r = u / C, k = u - r * C;
-        const float v = src[u];
-        if (k < 4) dst[r * 4 + k] = v;
-        else tailp[r * CB + (k - 4)] = v;
+    const int n = rows * C;
+    for (int u0 = threadIdx.x; u0 < n; u0 += BATCH * blockDim.x) {
+        float v[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int u = u0 + b * blockDim.x;
+            v[b] = u < n ? src[u] : 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int u = u0 + b * blockDim.x;
+            if (u < n) {
+                const int r = u / C, k = u - r * C;
+                if (k < 4) dst[r * 4 + k] = v[b];
+                else tailp[r * CB + (k - 4)] = v[b];
+            }
+        }
     }
     if constexpr (C < 4) {   // zero the unused columns (they are read as part of the float4)
         for (int u = threadIdx.x; u < rows * (4 - C); u += blockDim.x) {

@@ -658,22 +658,29 @@ __device__ __forceinline__ float row_elem(const float *cbl_base, int row, int k,
 }
 
 // NQ consecutive 1-KiB pieces by LDS-DMA with scalar addressing: global source = uniform base +
-// lane*16 (+1 KiB per piece as the immediate), LDS destination = M0 (+1 KiB per piece).  Written in
+// lane*16 + immediate, LDS destination = M0 + the SAME immediate + lane*16 (the instruction offset
+// applies to both sides: probed on hardware), so consecutive pieces need only a new immediate.  Written in
 // asm on purpose: after the builtin form hipcc puts s_waitcnt vmcnt(0) in front of the next ds_read,
 // which serialises the transfer with the quantise phase it is meant to hide behind (measured: the
 // builtin cost 0.4 ms per launch whether or not the quantise phase ran).  M0 is saved/restored; the
 // reader side waits with dma_wait_all() before the barrier that publishes the data.
 template <int NQ>
-__device__ __forceinline__ void dma_pieces(const float *g_uniform, unsigned lds_byte_addr, unsigned lane_byte_off)
+__device__ __forceinline__ void dma_pieces(const float *g_uniform_in, unsigned lds_byte_addr_in, unsigned lane_byte_off)
 {
     static_assert(NQ * 1024 <= 4096, "immediate offset range of global_load_lds");
+    // "s" operands must be provably wave-uniform for hipcc: say so explicitly
+    const unsigned long long ga = reinterpret_cast<unsigned long long>(g_uniform_in);
+    const unsigned long long gu = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga) |
+                                  ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32)) << 32);
+    const float *g_uniform = reinterpret_cast<const float *>(gu);
+    const unsigned lds_byte_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_addr_in);
     unsigned keep;
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
                      "global_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(lane_byte_off), "s"(g_uniform), "s"(lds_byte_addr + qd * 1024), "i"(qd * 1024)
+                     : "v"(lane_byte_off), "s"(g_uniform), "s"(lds_byte_addr), "i"(qd * 1024)
                      : "memory");
     }
 }
@@ -1196,6 +1203,7 @@ struct DecParams {
     float *out;
     long long n_tokens;
     int d, dp, c, K, nlev, nq, idx_dtype;
+    const float *rec_p;   // pass records (rqae_decode_lds_kernel reads the lin_out quads of record l+1)
     uint32_t mask[MAX_MASK_LEVELS / 32];
 };
 
@@ -1295,11 +1303,160 @@ int launch_decode(const DecParams &p, bool from_idx, hipStream_t stream)
     return 0;
 }
 
+
+// =============================================================== LDS-staged decode kernel
+// Decode has no dependency between levels and no cross-lane reduction: out = sum_l (lin_out_l(cv_l)),
+// ascending, first selected level assigns (rqae/model.py:236-248).  Same geometry as the encode
+// kernel (8 waves = 4 slices x 2 token halves, 8 tokens per wave, packed fp32 over token pairs); the
+// lin_out weights of a level are the first two quads of every element step of pass record l+1
+// (w_out[0..c-1], b_out), copied L2 -> LDS by LDS-DMA into one of TWO buffers, so level l+1 loads while
+// level l computes.  Codebook values of the tile (16 tokens x 32 levels x c) are gathered into LDS.
+template <int P, int C, bool FROM_IDX>
+__global__ void __launch_bounds__(512, 2)
+rqae_decode_lds_kernel(const DecParams p)
+{
+    constexpr int TPW = 8, NW = 8, TG = 16, NPAIR = 4, NG = 2, LCH = 32;
+    constexpr int QI = (2 * C + 1 + 3) / 4;      // quads per element step in the pass record
+    constexpr int QD = (C + 1 + 3) / 4;          // leading quads that hold w_out[0..C-1], b_out
+    static_assert(QD <= QI && QD * 1024 <= 4096, "decode reads a prefix of the record's quads");
+    constexpr int BUF = NSLICE * P * QD * 256;   // floats per weight buffer
+    constexpr int dp = 256 * P;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wbuf = smem;                          // [2][slice][i][QD][lane][4]
+    float *cvl = wbuf + 2 * BUF;                 // [LCH][C][TG]  (token pairs contiguous)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slice = wave & 3, half = wave >> 2;
+    const int ebase = slice * 64 * P + lane;
+    const long long tok0 = (long long)blockIdx.x * TG;
+    const long long tokw = tok0 + half * TPW;
+    const bool full_tile = (tokw + TPW <= p.n_tokens) && (p.d == dp);
+    const unsigned wbuf_addr = lds_addr_of(wbuf);
+
+    auto level_on = [&](int l) { return ((p.mask[l >> 5] >> (l & 31)) & 1u) != 0; };
+    auto next_on = [&](int l) { while (l < p.nlev && !level_on(l)) ++l; return l; };   // uniform scalar loop
+    // lin_out quads of level l (record l+1) -> buffer b; the 8 waves share the (slice, i) chunks
+    auto issue_dma = [&](int l, int b) {
+        const float *rec = p.rec_p + (size_t)(l + 1) * NSLICE * P * QI * 256;
+        for (int ch = wave; ch < NSLICE * P; ch += NW)
+            dma_pieces<QD>(rec + (size_t)ch * QI * 256, wbuf_addr + (b * BUF + ch * QD * 256) * 4, lane * 16);
+    };
+
+    f2 acc[P][NPAIR];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) acc[i][pr] = splat2(0.0f);
+    bool first = true;
+
+    int l = next_on(0), buf = 0;
+    if (l < p.nlev) issue_dma(l, 0);
+    int staged_from = -1;                         // first level of the codebook-value chunk in LDS
+    while (l < p.nlev) {
+        const int ln = next_on(l + 1);
+        if (l >= staged_from + LCH || staged_from < 0) {
+            // gather this tile's codebook values for levels [l, l+LCH)
+            if (staged_from >= 0) __syncthreads();            // previous chunk no longer read
+            staged_from = l;
+            for (int u = threadIdx.x; u < TG * LCH; u += blockDim.x) {
+                const int t = u % TG, ll = u / TG, lv = l + ll;
+                const long long tok = tok0 + t;
+                if (lv >= p.nlev || !level_on(lv) || tok >= p.n_tokens) continue;
+                const float *row;
+                if constexpr (FROM_IDX) {
+                    const long long ix = load_idx(p.src, p.idx_dtype, (size_t)tok * p.nq + lv);
+                    row = p.cb0 + (size_t)ix * C;             // level-0 codebook for every level (model.py:234)
+                } else {
+                    row = reinterpret_cast<const float *>(p.src) + ((size_t)tok * p.nq + lv) * C;
+                }
+#pragma unroll
+                for (int k = 0; k < C; ++k) cvl[(ll * C + k) * TG + t] = row[k];
+            }
+        }
+        dma_wait_all();
+        __syncthreads();                                      // weights of level l + codebook values visible
+        if (ln < p.nlev) issue_dma(ln, buf ^ 1);              // next selected level loads behind this one
+
+        const f4 *wl = reinterpret_cast<const f4 *>(wbuf + buf * BUF) + (size_t)slice * P * QD * 64 + lane;
+        const float *cvp = cvl + (l - staged_from) * C * TG + half * TPW;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f2 cv2[2][C];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const f2 v = *reinterpret_cast<const f2 *>(cvp + k * TG + 4 * g + 2 * pr);
+                    cv2[pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
+                }
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                float w[QD * 4];
+#pragma unroll
+                for (int qd = 0; qd < QD; ++qd) {
+                    const f4 v = wl[(i * QD + qd) * 64];
+                    w[4 * qd] = v.x; w[4 * qd + 1] = v.y; w[4 * qd + 2] = v.z; w[4 * qd + 3] = v.w;
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    f2 y = splat2(0.0f);
+#pragma unroll
+                    for (int k = 0; k < C; ++k) y = fma2(cv2[pr][k], splat2(w[k]), y);
+                    y = y + splat2(w[C]);
+                    if (first) acc[i][2 * g + pr] = y;         // first selected level assigns (model.py:244-247)
+                    else acc[i][2 * g + pr] = acc[i][2 * g + pr] + y;
+                }
+            }
+        }
+        first = false;
+        l = ln;
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const long long tok = tokw + t;
+        float *op = p.out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d + ebase;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float v = (t & 1) ? acc[i][t >> 1].y : acc[i][t >> 1].x;
+            if (full_tile) op[64 * i] = v;
+            else if (tok < p.n_tokens && ebase + 64 * i < p.d) op[64 * i] = v;
+        }
+    }
+}
+
+template <int P, int C>
+int launch_decode_lds(const DecParams &p, bool from_idx, hipStream_t stream)
+{
+    constexpr int QD = (C + 1 + 3) / 4;
+    const size_t lds = sizeof(float) * (2 * (size_t)NSLICE * P * QD * 256 + 32 * C * 16);
+    const long long nblk = (p.n_tokens + 15) / 16;
+    if (nblk > 0x7fffffffLL) return fail("decode: too many tokens for one launch");
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, stream, p);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if (from_idx) return go(rqae_decode_lds_kernel<P, C, true>);
+    return go(rqae_decode_lds_kernel<P, C, false>);
+}
+
 int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t stream)
 {
 #ifdef RQAE_EXPERIMENT_ONLY_95
     return fail("experiment build");
 #else
+    if (env_variant() == V_AUTO) {
+        if (P == 9 && c == 5) return launch_decode_lds<9, 5>(p, from_idx, stream);
+        if (P == 9 && c == 4) return launch_decode_lds<9, 4>(p, from_idx, stream);
+        if (P == 1 && c == 4) return launch_decode_lds<1, 4>(p, from_idx, stream);
+    }
     if (env_variant() != V_GEN) {
         if (P == 9 && c == 5) return launch_decode<9, 5, 16, false>(p, from_idx, stream);
         if (P == 9 && c == 4) return launch_decode<9, 4, 16, false>(p, from_idx, stream);
@@ -1356,7 +1513,7 @@ int decode_common(const void *packed, int d, int c, int K, int L, const void *sr
         top = l + 1;
     }
     if (!used) return fail("decode: no level selected");
-    p.w_out = v.w_out; p.b_out = v.b_out; p.cb0 = v.cb;
+    p.w_out = v.w_out; p.b_out = v.b_out; p.cb0 = v.cb; p.rec_p = v.rec_p;
     p.src = src; p.out = out; p.n_tokens = n_tokens;
     p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.nlev = top; p.nq = nq; p.idx_dtype = idx_dtype;
     return dispatch_decode(v.dp / 256, c, p, from_idx, static_cast<hipStream_t>(stream));

@@ -24,7 +24,7 @@
  *   - lin_in (length-d dot): ATen's blocked GEMM order is not specified, so the
  *     order is DEFINED here ("canonical order"): d is
  *     zero-padded to a multiple of 256 and cut into 4 contiguous slices of
- *     64*P elements; element s*64P + 64*i + lane belongs to (slice s, lane);
+ *     64*P elements; elem_of(P, s, i, lane) belongs to (slice s, lane, step i);
  *     each (slice, lane) runs an fmaf chain over i = 0..P-1 from +0; the 64
  *     lanes of a slice are summed by the tree in lane_tree(); the slices are
  *     summed ((s0+s1)+(s2+s3)); the bias is added last.
@@ -158,21 +158,38 @@ static void unpack(packed_t *p)
     free(p->w_in); free(p->w_outT); free(p->b_out); free(p->cbT);
 }
 
+/* Canonical lane<->element map.  Slice s owns elements [s*64P, (s+1)*64P).
+ * Inside a slice the P element steps of a lane are grouped so that a lane's elements are contiguous
+ * in memory in runs of 4, then 2, then 1 (wide loads/stores on the GPU):
+ *   steps i <  4*floor(P/4)            : block of 256 elements per 4 steps, lane owns 4*lane + (i%4)
+ *   next 2 steps if at least 2 remain  : block of 128 elements,            lane owns 2*lane + j
+ *   last step if one remains           : block of 64 elements,             lane owns lane
+ * The fma chain of a lane still runs over i = 0..P-1 in ascending order. */
+static inline int elem_of(int P, int s, int i, int lane)
+{
+    const int base = s * 64 * P;
+    const int q4 = (P / 4) * 4;
+    if (i < q4) return base + 256 * (i / 4) + 4 * lane + (i % 4);
+    const int rem = P - q4, j = i - q4;
+    if (rem >= 2 && j < 2) return base + 64 * q4 + 2 * lane + j;
+    return base + 64 * q4 + (rem >= 2 ? 128 : 0) + lane;
+}
+
 /* lin_in of one token at one level in the canonical order (see header). */
 static void lin_in_canonical(const packed_t *p, int l, const float *r, float *q)
 {
     const int P = p->P, dp = p->dp, c = p->c;
-    const int slice_len = NLANE * P;
     for (int j = 0; j < c; ++j) {
         const float *w = p->w_in + ((size_t)l * c + j) * dp;
         float t[NSLICE];
         for (int s = 0; s < NSLICE; ++s) {
             float part[NLANE];
             for (int ln = 0; ln < NLANE; ++ln) part[ln] = 0.0f;
-            const float *rs = r + s * slice_len, *ws = w + s * slice_len;
             for (int i = 0; i < P; ++i)
-                for (int ln = 0; ln < NLANE; ++ln)
-                    part[ln] = fmaf(rs[64 * i + ln], ws[64 * i + ln], part[ln]);
+                for (int ln = 0; ln < NLANE; ++ln) {
+                    const int e = elem_of(P, s, i, ln);
+                    part[ln] = fmaf(r[e], w[e], part[ln]);
+                }
             t[s] = lane_tree(part);
         }
         q[j] = ((t[0] + t[1]) + (t[2] + t[3])) + p->b_in[(size_t)l * c + j];

@@ -10,7 +10,7 @@
 //   * everything is fp32, one rounding per written operation; compiled with
 //     -ffp-contract=off, fused multiply-adds appear only as explicit fmaf()
 //   * lin_in  : d is zero-padded to dp = 256*P and cut into 4 slices of 64*P;
-//               element s*64P + 64*i + lane belongs to (slice s, lane); each
+//               element elem_of(P, s, i, lane) belongs to (slice s, lane, step i); each
 //               (slice, lane) runs a fmaf chain over i from +0; the 64 lanes are
 //               summed by the pairing lane^32, lane^16, lane^8, 7-mirror, lane^1,
 //               lane^2; slices as ((s0+s1)+(s2+s3)); bias last
@@ -113,6 +113,19 @@ Layout make_layout(int d, int c, int K, int L)
     return lo;
 }
 
+// Canonical lane<->element map (identical to elem_of in oracle/rqae_oracle.c):
+// slice s owns [s*64P, (s+1)*64P); a lane's P element steps are laid out in memory in runs of 4, then
+// 2, then 1 consecutive elements, so tiles load and store with dwordx4 / dwordx2.
+__host__ __device__ __forceinline__ int elem_of(int P, int s, int i, int lane)
+{
+    const int base = s * 64 * P;
+    const int q4 = (P / 4) * 4;
+    if (i < q4) return base + 256 * (i / 4) + 4 * lane + (i % 4);
+    const int rem = P - q4, j = i - q4;
+    if (rem >= 2 && j < 2) return base + 64 * q4 + 2 * lane + j;
+    return base + 64 * q4 + (rem >= 2 ? 128 : 0) + lane;
+}
+
 bool shape_ok(int d, int c, int K, int L)
 {
     return d >= 1 && d <= MAX_D && c >= 1 && c <= MAX_C && K >= 1 && L >= 1;
@@ -133,7 +146,7 @@ __global__ void pack_records_kernel(Header h, int qi, float *rec_p, const float 
         const int slice = (int)(rest & 3);
         const size_t pl = rest >> 2;
         const int n = quad * 4 + e4;
-        const int el = slice * 64 * P + 64 * i + lane;
+        const int el = elem_of(P, slice, i, lane);
         float val = 0.0f;
         if (el < h.d) {
             if (n < h.c) { if (pl >= 1) val = w_out[((pl - 1) * h.d + el) * h.c + n]; }
@@ -367,6 +380,7 @@ struct EncParams {
     long long n_tokens;
     int d, dp, c, K, levels, x_dtype;
     int kch;  // codebook rows staged in LDS per chunk (multiple of 64, or >= K)
+    int aligned16;  // x and q_out 16-byte aligned: full tiles may use vector loads/stores
     int ablate;  // RQAE_HIP_ABLATE bits: timing experiments only, results are wrong when != 0
 };
 
@@ -395,7 +409,7 @@ rqae_encode_kernel(const EncParams p)
     const int cp = GEN ? p.c : C;
     const int Pp = GEN ? p.dp / 256 : P;
     const int dp = GEN ? p.dp : 256 * P;
-    const int ebase = slice * 64 * Pp + lane;          // element of (i = 0)
+    auto el = [&](int i) { return elem_of(Pp, slice, i, lane); };   // this lane's element at step i
     const long long tok0 = (long long)blockIdx.x * TG;  // first token of the workgroup
     const long long tokw = tok0 + half * TPW;           // first token of this wave
 
@@ -409,7 +423,7 @@ rqae_encode_kernel(const EncParams p)
     for (int i = 0; i < P; ++i)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int e = ebase + 64 * i;
+            const int e = el(i);
             const long long tok = tokw + t;
             const bool ok = (!GEN || i < Pp) && e < p.d && tok < p.n_tokens;
             r[i][t] = ok ? load_x(p.x, p.x_dtype, (size_t)tok * p.d + e) : 0.0f;
@@ -422,13 +436,13 @@ rqae_encode_kernel(const EncParams p)
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = 0.0f;
         {
-            const float *wl = p.w_in + (size_t)l * cp * dp + ebase;
+            const float *wl = p.w_in + (size_t)l * cp * dp;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 if (GEN && i >= Pp) continue;
                 float w[C];
 #pragma unroll
-                for (int j = 0; j < C; ++j) w[j] = (!GEN || j < cp) ? wl[(size_t)j * dp + 64 * i] : 0.0f;
+                for (int j = 0; j < C; ++j) w[j] = (!GEN || j < cp) ? wl[(size_t)j * dp + el(i)] : 0.0f;
 #pragma unroll
                 for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -511,15 +525,15 @@ rqae_encode_kernel(const EncParams p)
             for (int t = 0; t < TPW; ++t)
 #pragma unroll
                 for (int k = 0; k < C; ++k) cv[t][k] = cvs[(half * TPW + t) * C + k];
-            const float *wl = p.w_out + (size_t)l * cp * dp + ebase;
-            const float *bl = p.b_out + (size_t)l * dp + ebase;
+            const float *wl = p.w_out + (size_t)l * cp * dp;
+            const float *bl = p.b_out + (size_t)l * dp;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 if (GEN && i >= Pp) continue;
                 float w[C];
 #pragma unroll
-                for (int k = 0; k < C; ++k) w[k] = (!GEN || k < cp) ? wl[(size_t)k * dp + 64 * i] : 0.0f;
-                const float b = bl[64 * i];
+                for (int k = 0; k < C; ++k) w[k] = (!GEN || k < cp) ? wl[(size_t)k * dp + el(i)] : 0.0f;
+                const float b = bl[el(i)];
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
                     float y = 0.0f;
@@ -541,7 +555,7 @@ rqae_encode_kernel(const EncParams p)
         for (int i = 0; i < P; ++i)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const int e = ebase + 64 * i;
+                const int e = el(i);
                 const long long tok = tokw + t;
                 if ((!GEN || i < Pp) && e < p.d && tok < p.n_tokens) p.q_out[(size_t)tok * p.d + e] = out[i][t];
             }
@@ -561,21 +575,63 @@ __device__ __forceinline__ float widen<uint16_t>(uint16_t v) { return __builtin_
 template <>
 __device__ __forceinline__ float widen<_Float16>(_Float16 v) { return (float)v; }
 
+template <typename XT, int N>
+struct VecOf { typedef XT type __attribute__((ext_vector_type(N))); };
+
+// One token row segment -> registers.  FULL: the lane's runs of 4 / 2 / 1 consecutive elements are
+// fetched with one load each (elem_of); otherwise element by element with bounds predicates.
 template <int P, int TPW, typename XT, bool FULL>
 __device__ __forceinline__ void load_tile(float (&dst)[P][TPW], const XT *x, long long tokw, long long n_tokens,
-                                          int d, int ebase)
+                                          int d, int slice, int lane)
 {
+    constexpr int Q4 = (P / 4) * 4, REM = P - Q4;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const long long tok = tokw + t;
-        const XT *xp = x + (size_t)(FULL ? tok : (tok < n_tokens ? tok : 0)) * d + ebase;
+        const XT *xr = x + (size_t)(FULL ? tok : (tok < n_tokens ? tok : 0)) * d;
+        if constexpr (FULL) {
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            if constexpr (FULL) dst[i][t] = widen<XT>(xp[64 * i]);
-            else dst[i][t] = (tok < n_tokens && ebase + 64 * i < d) ? widen<XT>(xp[64 * i]) : 0.0f;
+            for (int q = 0; q < Q4; q += 4) {
+                const auto v = *reinterpret_cast<const typename VecOf<XT, 4>::type *>(xr + elem_of(P, slice, q, lane));
+                dst[q][t] = widen<XT>(v.x); dst[q + 1][t] = widen<XT>(v.y);
+                dst[q + 2][t] = widen<XT>(v.z); dst[q + 3][t] = widen<XT>(v.w);
+            }
+            if constexpr (REM >= 2) {
+                const auto v = *reinterpret_cast<const typename VecOf<XT, 2>::type *>(xr + elem_of(P, slice, Q4, lane));
+                dst[Q4][t] = widen<XT>(v.x); dst[Q4 + 1][t] = widen<XT>(v.y);
+            }
+            if constexpr (REM & 1) dst[P - 1][t] = widen<XT>(xr[elem_of(P, slice, P - 1, lane)]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int e = elem_of(P, slice, i, lane);
+                dst[i][t] = (tok < n_tokens && e < d) ? widen<XT>(xr[e]) : 0.0f;
+            }
         }
     }
 }
+
+// Store the run of a lane's consecutive elements that ends at element step i (if one ends there):
+// v(k) yields the value of step k.  row = start of the token's output row.
+template <int P, typename F>
+__device__ __forceinline__ void store_run_ending_at(float *row, int slice, int lane, int i, F v)
+{
+    constexpr int Q4 = (P / 4) * 4, REM = P - Q4;
+    if (i < Q4) {
+        if ((i & 3) == 3) {
+            typedef float f4s __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<f4s *>(row + elem_of(P, slice, i - 3, lane)) = (f4s){v(i - 3), v(i - 2), v(i - 1), v(i)};
+        }
+    } else if (REM >= 2 && i - Q4 < 2) {
+        if (i - Q4 == 1) {
+            typedef float f2s __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f2s *>(row + elem_of(P, slice, Q4, lane)) = (f2s){v(i - 1), v(i)};
+        }
+    } else {
+        row[elem_of(P, slice, i, lane)] = v(i);
+    }
+}
+
 
 
 // =============================================================== LDS-staged encode kernel
@@ -716,7 +772,6 @@ rqae_encode_lds_kernel(const EncParams p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slice = wave & 3;
     const int half = wave >> 2;
-    const int ebase = slice * 64 * P + lane;
     const long long tok0 = (long long)blockIdx.x * TG;
     const long long tokw = tok0 + half * TPW;
 
@@ -743,17 +798,17 @@ rqae_encode_lds_kernel(const EncParams p)
 
     f2 r2[P][NPAIR];
     f2 out2[RECON ? P : 1][RECON ? NPAIR : 1];
-    const bool full_tile = (tokw + TPW <= p.n_tokens) && (p.d == dp);  // wave-uniform
+    const bool full_tile = (tokw + TPW <= p.n_tokens) && (p.d == dp) && p.aligned16;  // wave-uniform: vector loads/stores
     {
         float xt[P][TPW];
         if (full_tile) {
-            if (p.x_dtype == RQAE_X_BF16) load_tile<P, TPW, uint16_t, true>(xt, (const uint16_t *)p.x, tokw, p.n_tokens, p.d, ebase);
-            else if (p.x_dtype == RQAE_X_F32) load_tile<P, TPW, float, true>(xt, (const float *)p.x, tokw, p.n_tokens, p.d, ebase);
-            else load_tile<P, TPW, _Float16, true>(xt, (const _Float16 *)p.x, tokw, p.n_tokens, p.d, ebase);
+            if (p.x_dtype == RQAE_X_BF16) load_tile<P, TPW, uint16_t, true>(xt, (const uint16_t *)p.x, tokw, p.n_tokens, p.d, slice, lane);
+            else if (p.x_dtype == RQAE_X_F32) load_tile<P, TPW, float, true>(xt, (const float *)p.x, tokw, p.n_tokens, p.d, slice, lane);
+            else load_tile<P, TPW, _Float16, true>(xt, (const _Float16 *)p.x, tokw, p.n_tokens, p.d, slice, lane);
         } else {
-            if (p.x_dtype == RQAE_X_BF16) load_tile<P, TPW, uint16_t, false>(xt, (const uint16_t *)p.x, tokw, p.n_tokens, p.d, ebase);
-            else if (p.x_dtype == RQAE_X_F32) load_tile<P, TPW, float, false>(xt, (const float *)p.x, tokw, p.n_tokens, p.d, ebase);
-            else load_tile<P, TPW, _Float16, false>(xt, (const _Float16 *)p.x, tokw, p.n_tokens, p.d, ebase);
+            if (p.x_dtype == RQAE_X_BF16) load_tile<P, TPW, uint16_t, false>(xt, (const uint16_t *)p.x, tokw, p.n_tokens, p.d, slice, lane);
+            else if (p.x_dtype == RQAE_X_F32) load_tile<P, TPW, float, false>(xt, (const float *)p.x, tokw, p.n_tokens, p.d, slice, lane);
+            else load_tile<P, TPW, _Float16, false>(xt, (const _Float16 *)p.x, tokw, p.n_tokens, p.d, slice, lane);
         }
 #pragma unroll
         for (int i = 0; i < P; ++i)
@@ -839,8 +894,8 @@ rqae_encode_lds_kernel(const EncParams p)
                                 if (full_tile) {
                                     const int t0 = 4 * g + 2 * pr;
                                     float *o0 = p.q_out + (size_t)(tokw + t0) * p.d;
-                                    o0[ebase + 64 * i] = out2[i][2 * g + pr].x;
-                                    o0[(size_t)p.d + ebase + 64 * i] = out2[i][2 * g + pr].y;
+                                    store_run_ending_at<P>(o0, slice, lane, i, [&](int k) { return out2[k][2 * g + pr].x; });
+                                    store_run_ending_at<P>(o0 + p.d, slice, lane, i, [&](int k) { return out2[k][2 * g + pr].y; });
                                 }
                             }
                         }
@@ -1011,11 +1066,12 @@ rqae_encode_lds_kernel(const EncParams p)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const long long tok = tokw + t;
-                float *op = p.q_out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d + ebase;
+                float *op = p.q_out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d;
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
                     const float v = (t & 1) ? out2[i][t >> 1].y : out2[i][t >> 1].x;
-                    if (tok < p.n_tokens && ebase + 64 * i < p.d) op[64 * i] = v;
+                    const int e = elem_of(P, slice, i, lane);
+                    if (tok < p.n_tokens && e < p.d) op[e] = v;
                 }
             }
         }
@@ -1204,6 +1260,7 @@ struct DecParams {
     long long n_tokens;
     int d, dp, c, K, nlev, nq, idx_dtype;
     const float *rec_p;   // pass records (rqae_decode_lds_kernel reads the lin_out quads of record l+1)
+    int aligned16;        // out 16-byte aligned: full tiles use vector stores
     uint32_t mask[MAX_MASK_LEVELS / 32];
 };
 
@@ -1227,7 +1284,7 @@ rqae_decode_kernel(const DecParams p)
     const int cp = GEN ? p.c : C;
     const int Pp = GEN ? p.dp / 256 : P;
     const int dp = GEN ? p.dp : 256 * P;
-    const int ebase = slice * 64 * Pp + lane;
+    auto el = [&](int i) { return elem_of(Pp, slice, i, lane); };
     const long long tok0 = (long long)blockIdx.x * TPW;
 
     float acc[P][TPW];
@@ -1258,15 +1315,15 @@ rqae_decode_kernel(const DecParams p)
         for (int ll = 0; ll < lch; ++ll) {
             const int l = l0 + ll;
             if (!((p.mask[l >> 5] >> (l & 31)) & 1u)) continue;
-            const float *wl = p.w_out + (size_t)l * cp * dp + ebase;
-            const float *bl = p.b_out + (size_t)l * dp + ebase;
+            const float *wl = p.w_out + (size_t)l * cp * dp;
+            const float *bl = p.b_out + (size_t)l * dp;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 if (GEN && i >= Pp) continue;
                 float w[C];
 #pragma unroll
-                for (int k = 0; k < C; ++k) w[k] = (!GEN || k < cp) ? wl[(size_t)k * dp + 64 * i] : 0.0f;
-                const float b = bl[64 * i];
+                for (int k = 0; k < C; ++k) w[k] = (!GEN || k < cp) ? wl[(size_t)k * dp + el(i)] : 0.0f;
+                const float b = bl[el(i)];
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
                     float y = 0.0f;
@@ -1284,7 +1341,7 @@ rqae_decode_kernel(const DecParams p)
     for (int i = 0; i < P; ++i)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int e = ebase + 64 * i;
+            const int e = el(i);
             const long long tok = tok0 + t;
             if ((!GEN || i < Pp) && e < p.d && tok < p.n_tokens) p.out[(size_t)tok * p.d + e] = acc[i][t];
         }
@@ -1329,10 +1386,9 @@ rqae_decode_lds_kernel(const DecParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slice = wave & 3, half = wave >> 2;
-    const int ebase = slice * 64 * P + lane;
     const long long tok0 = (long long)blockIdx.x * TG;
     const long long tokw = tok0 + half * TPW;
-    const bool full_tile = (tokw + TPW <= p.n_tokens) && (p.d == dp);
+    const bool full_tile = (tokw + TPW <= p.n_tokens) && (p.d == dp) && p.aligned16;
     const unsigned wbuf_addr = lds_addr_of(wbuf);
 
     auto level_on = [&](int l) { return ((p.mask[l >> 5] >> (l & 31)) & 1u) != 0; };
@@ -1418,12 +1474,15 @@ rqae_decode_lds_kernel(const DecParams p)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const long long tok = tokw + t;
-        float *op = p.out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d + ebase;
+        float *op = p.out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d;
+        auto val = [&](int k) { return (t & 1) ? acc[k][t >> 1].y : acc[k][t >> 1].x; };
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const float v = (t & 1) ? acc[i][t >> 1].y : acc[i][t >> 1].x;
-            if (full_tile) op[64 * i] = v;
-            else if (tok < p.n_tokens && ebase + 64 * i < p.d) op[64 * i] = v;
+            if (full_tile) store_run_ending_at<P>(op, slice, lane, i, val);
+            else {
+                const int e = elem_of(P, slice, i, lane);
+                if (tok < p.n_tokens && e < p.d) op[e] = val(i);
+            }
         }
     }
 }
@@ -1516,6 +1575,7 @@ int decode_common(const void *packed, int d, int c, int K, int L, const void *sr
     p.w_out = v.w_out; p.b_out = v.b_out; p.cb0 = v.cb; p.rec_p = v.rec_p;
     p.src = src; p.out = out; p.n_tokens = n_tokens;
     p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.nlev = top; p.nq = nq; p.idx_dtype = idx_dtype;
+    p.aligned16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     return dispatch_decode(v.dp / 256, c, p, from_idx, static_cast<hipStream_t>(stream));
 }
 
@@ -1576,6 +1636,7 @@ int rqae_hip_encode(const void *packed, int d, int c, int K, int L, const void *
     p.rec_p = v.rec_p;
     p.x = x; p.q_out = q_out; p.idx = reinterpret_cast<long long *>(indices);
     p.n_tokens = n_tokens; p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.levels = levels; p.x_dtype = x_dtype;
+    p.aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q_out)) & 15) == 0;
     int rc = 0;
     dispatch_encode(v.dp / 256, c, packed_has_shared_codebook(packed), &p, static_cast<hipStream_t>(stream), &rc);
     return rc;

@@ -272,3 +272,65 @@ def test_full_size_properties():
     q_o, idx_o = oracle.forward(xs, w)
     assert np.array_equal(idx[0, sel].cpu().numpy(), idx_o)
     assert np.array_equal(q[0, sel].cpu().numpy(), q_o)
+
+
+def test_nonfinite_and_zero_rows_follow_argmax_rule():
+    """Zero / NaN / inf rows: the projection or its normalisation is NaN, every similarity is NaN and
+    torch.argmax returns 0 at that level (rqae/model.py:182,188); later levels continue from the
+    (finite) straight-through value.  Neighbouring tokens must be unaffected."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(17, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    x = synth.activations(3, 64, cfg["dim"])
+    x[5] = 0.0
+    x[9, 100] = np.inf
+    x[33, 7] = np.nan
+    x[40] = 1e-30
+    q, idx = run_forward(make_model(cfg, w), x)
+    q_o, idx_o = oracle.forward(x, w)
+    assert np.array_equal(idx, idx_o)
+    assert np.array_equal(q, q_o, equal_nan=True)
+    assert idx[33].tolist() == [0] * 8 and idx[9].tolist() == [0] * 8      # NaN / inf never recover
+    clean = [i for i in range(64) if i not in (9, 33)]
+    assert np.isfinite(q[clean]).all()
+
+
+def test_unaligned_views_take_the_scalar_path():
+    """x / q_out that are not 16-byte aligned (a view starting mid-buffer) must give the same bits."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(23, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    n, d = 48, cfg["dim"]
+    x = synth.round_to_bf16(synth.activations(4, n, d))
+    buf = torch.zeros(n * d + 8, dtype=torch.bfloat16, device=DEV)
+    view = buf[1:1 + n * d].view(1, n, d)                      # 2-byte offset
+    view.copy_(torch.from_numpy(x).to(torch.bfloat16).view(1, n, d))
+    assert view.data_ptr() % 16 != 0
+    with torch.inference_mode():
+        q, idx = m(view)
+        qa, ia = m(torch.from_numpy(x).to(DEV).to(torch.bfloat16).view(1, n, d))
+    assert torch.equal(idx, ia) and torch.equal(q, qa)
+    q_o, idx_o = oracle.forward(x, w)
+    assert np.array_equal(idx[0].cpu().numpy(), idx_o) and np.array_equal(q[0].cpu().numpy(), q_o)
+
+
+def test_decode_full_size_and_uint16_codes():
+    """Decode at BASELINE size: uint16 / int32 / int64 code matrices give the same bits, the level
+    whitelist is additive in the reference's order, and a strided sample matches the oracle."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    n = 262144
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    idx = torch.randint(0, 1024, (1, n, 8), device=DEV, generator=g)
+    with torch.inference_mode():
+        d64 = m.decode(idx)
+        d32 = m.decode(idx.to(torch.int32))
+        d16 = m.decode(idx.to(torch.uint16))
+        assert torch.equal(d64, d32) and torch.equal(d64, d16)
+        d0 = m.decode(idx, layers=[0])
+        d1 = m.decode(idx, layers=[1])
+        d01 = m.decode(idx, layers=[0, 1])
+        assert torch.equal(d0 + d1, d01)                      # first level assigns, second adds
+    sel = np.arange(0, n, 1009)
+    ref = oracle.decode(idx[0, sel].cpu().numpy(), w)
+    assert np.array_equal(d64[0, sel].cpu().numpy(), ref)

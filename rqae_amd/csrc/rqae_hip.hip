@@ -31,9 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <mutex>
 #include <type_traits>
-#include <unordered_map>
 
 #include "../../include/rqae_hip.h"
 
@@ -65,23 +63,6 @@ int fail(const char *fmt, ...)
     } while (0)
 
 // ---------------------------------------------------------------- packed block
-// Host-side note of what rqae_hip_pack was told about each block it built (the header itself
-// lives in device memory and is only read by kernels).  Unknown pointer => assume per-level codebooks.
-std::mutex g_reg_mutex;
-std::unordered_map<const void *, int> g_shared_cb;
-
-void note_packed(const void *packed, int shared)
-{
-    std::lock_guard<std::mutex> lk(g_reg_mutex);
-    g_shared_cb[packed] = shared;
-}
-bool packed_has_shared_codebook(const void *packed)
-{
-    std::lock_guard<std::mutex> lk(g_reg_mutex);
-    auto it = g_shared_cb.find(packed);
-    return it != g_shared_cb.end() && it->second != 0;
-}
-
 struct Header {
     int magic, d, c, K, L, dp, shared_cb, pad;
 };
@@ -978,9 +959,15 @@ rqae_encode_lds_kernel(const EncParams p)
                 if (in && s0 > best[0]) { best[0] = s0; bidx[0] = row_base + row; }
                 if (in && s1 > best[1]) { best[1] = s1; bidx[1] = row_base + row; }
             };
-            const int full = rows & ~63;
-#pragma unroll 4
-            for (int r0 = 0; r0 < full; r0 += 64) scan_block(r0, true);
+            // four 64-row blocks per trip, written out (hipcc will not unroll this loop on request)
+            const int full4 = rows & ~255, full = rows & ~63;
+            for (int r0 = 0; r0 < full4; r0 += 256) {
+                scan_block(r0, true);
+                scan_block(r0 + 64, true);
+                scan_block(r0 + 128, true);
+                scan_block(r0 + 192, true);
+            }
+            for (int r0 = full4; r0 < full; r0 += 64) scan_block(r0, true);
             if (full < rows) scan_block(full, full + lane < rows);
         }
         // wave-wide first maximum per token: max by reduce-scatter, then the lowest row among its holders
@@ -1156,13 +1143,13 @@ Variant env_variant()
 }
 
 // Which instantiation serves (P, c).  Returns a name; launches when p != nullptr.
-const char *dispatch_encode(int P, int c, bool shared_cb, const EncParams *p, hipStream_t stream, int *rc)
+const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream, int *rc)
 {
     const Variant v = env_variant();
 #ifdef RQAE_EXPERIMENT_ONLY_95   // compile-time experiments: one instantiation, fast rebuilds
     {
         if (p) *rc = launch_encode_lds<9, 5>(*p, stream, v == V_M);
-        (void)shared_cb; (void)v; (void)P; (void)c;
+        (void)v; (void)P; (void)c;
         return "experiment";
     }
 #else
@@ -1616,7 +1603,6 @@ int rqae_hip_pack(void *packed, int d, int c, int K, int L, const float *w_in, c
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b + lo.b_in, b_in, sizeof(float) * (size_t)L * c, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(b + lo.cb, codebook, sizeof(float) * (size_t)L * K * c, hipMemcpyDeviceToDevice, s));
-    note_packed(packed, codebook_shared ? 1 : 0);
     return 0;
 }
 
@@ -1638,7 +1624,7 @@ int rqae_hip_encode(const void *packed, int d, int c, int K, int L, const void *
     p.n_tokens = n_tokens; p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.levels = levels; p.x_dtype = x_dtype;
     p.aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q_out)) & 15) == 0;
     int rc = 0;
-    dispatch_encode(v.dp / 256, c, packed_has_shared_codebook(packed), &p, static_cast<hipStream_t>(stream), &rc);
+    dispatch_encode(v.dp / 256, c, &p, static_cast<hipStream_t>(stream), &rc);
     return rc;
 }
 
@@ -1647,7 +1633,7 @@ int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen)
     if (!shape_ok(d, c, K, L)) return fail("kernel_info: unsupported shape");
     if (!buf || !buflen) return fail("kernel_info: null buffer");
     int rc = 0;
-    const char *name = dispatch_encode(((d + 255) / 256), c, true, nullptr, nullptr, &rc);
+    const char *name = dispatch_encode(((d + 255) / 256), c, nullptr, nullptr, &rc);
     snprintf(buf, buflen, "%s", name);
     return 0;
 }

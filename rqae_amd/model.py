@@ -136,10 +136,29 @@ class RQAE(nn.Module):
         return (self._dim, self.codebook_dim, self.codebook.shape[1], self.num_quantizers)
 
     def _weights_key(self):
+        """Cheap fingerprint of the parameters the packed block was built from.
+
+        In eval mode (the only mode the hot path serves) parameters change through
+        ``load_state_dict`` / ``.to()`` -- both drop the cache explicitly -- so the fingerprint is the
+        device, two data pointers and the version counters of the first and last level: O(1) per call
+        (the pretrained model has 4096 parameter tensors; walking them costs more than a 512-token
+        encode).  In training mode every tensor's version counter is summed.  ``invalidate_packed()``
+        forces a rebuild after any other in-place edit.
+        """
+        first, last = self.layers[0], self.layers[-1]
         ver = self.codebook._version
-        for lin_in, lin_out in self.layers:
-            ver += lin_in.weight._version + lin_in.bias._version + lin_out.weight._version + lin_out.bias._version
-        return (self.codebook.device, self.codebook.data_ptr(), self.layers[0][0].weight.data_ptr(), ver)
+        if self.training:
+            for lin_in, lin_out in self.layers:
+                ver += lin_in.weight._version + lin_in.bias._version + lin_out.weight._version + lin_out.bias._version
+        else:
+            for lin in (first[0], first[1], last[0], last[1]):
+                ver += lin.weight._version + lin.bias._version
+        return (self.codebook.device, self.training, self.codebook.data_ptr(), first[0].weight.data_ptr(),
+                last[1].weight.data_ptr(), ver)
+
+    def invalidate_packed(self):
+        """Drop the packed parameter block (call after editing parameters in place in eval mode)."""
+        self._packed = None
 
     def _stacked(self):
         w_in = torch.stack([l[0].weight for l in self.layers]).float().contiguous()

@@ -96,6 +96,22 @@ int rqae_hip_decode_values(const void *packed, int d, int c, int K, int L, const
                            int64_t n_tokens, int nq, const uint8_t *level_mask, float *out,
                            void *stream);
 
+/*
+ * The step either side of forward() inside RQAE.hook (rqae/model.py:276-289) when the LLM is Gemma-2
+ * (rqae/llm.py:65-73).  hs is the hooked layer's output [n_tokens][d] in hs_dtype (RQAE_X_*).
+ *   rqae_hip_gemma_norm:  normed = (float(hs) * rsqrt(mean(hs^2) + eps)) * (1 + norm_weight)   fp32 [n][d]
+ *                         inv_rms[n] = rsqrt(mean(hs^2) + eps)   (kept for the way back)
+ *   rqae_hip_gemma_denorm_patch:  new = (q_out / (1 + norm_weight)) / inv_rms; rows with token %
+ *                         seq_len == 0 keep hs when skip_bos != 0 (rqae/model.py:285-286); new is written
+ *                         back into hs_inout in its own dtype (rqae/model.py:289) and, if new_out != NULL,
+ *                         also as fp32 [n][d] (what the reference hands to store("new", ...)).
+ */
+int rqae_hip_gemma_norm(const void *hs, int hs_dtype, const float *norm_weight, float eps, int64_t n_tokens,
+                        int d, float *normed, float *inv_rms, void *stream);
+int rqae_hip_gemma_denorm_patch(const float *q_out, const float *norm_weight, const float *inv_rms,
+                                int64_t n_tokens, int d, int seq_len, int skip_bos, void *hs_inout,
+                                int hs_dtype, float *new_out, void *stream);
+
 /* Human-readable name of the encode kernel variant chosen for a shape. */
 int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);
 

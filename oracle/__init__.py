@@ -12,4 +12,6 @@ from .oracle import (  # noqa: F401
     gemma_norm,
     gemma_denorm,
     hook_reference,
+    gemma_norm_canonical,
+    gemma_denorm_canonical,
 )

@@ -158,3 +158,41 @@ def hook_reference(hs16, w, norm_weight, skip_bos=True):
     if skip_bos:
         new[:, 0] = hs[:, 0]
     return dict(original=hs, normed=normed, quantized=q, indices=idx, new=new)
+
+
+def _lane_tree(v):
+    """The 64-lane pairing of rqae_oracle.c:lane_tree on float32 arrays shaped [..., 64]."""
+    a = (v[..., :32] + v[..., 32:]).astype(np.float32)
+    b = (a[..., :16] + a[..., 16:]).astype(np.float32)
+    c = (b[..., :8] + b[..., 8:]).astype(np.float32)
+    u = (c[..., :4] + c[..., 7:3:-1]).astype(np.float32)
+    return ((u[..., 0] + u[..., 1]).astype(np.float32) + (u[..., 2] + u[..., 3]).astype(np.float32)).astype(np.float32)
+
+
+def gemma_norm_canonical(hs, weight, eps=1e-6):
+    """rqae_hip_gemma_norm restated: lane owns elements 4*(lane + 64*j) + {0..3}, fma chain of squares per
+    lane, lane tree, / d, rs = 1/sqrt(ms + eps); normed = (x * rs) * (1 + w).  Returns (normed, rs)."""
+    x = np.asarray(hs).astype(np.float32)
+    lead, d = x.shape[:-1], x.shape[-1]
+    x2 = x.reshape(-1, d)
+    n = x2.shape[0]
+    dp = ((d + 255) // 256) * 256
+    xp = np.zeros((n, dp), np.float32); xp[:, :d] = x2
+    blocks = xp.reshape(n, dp // 256, 64, 4)           # [token][j][lane][u]
+    ss = np.zeros((n, 64), np.float32)
+    for j in range(dp // 256):
+        for u in range(4):
+            v = blocks[:, j, :, u]
+            ss = (v.astype(np.float64) * v.astype(np.float64) + ss.astype(np.float64)).astype(np.float32)
+    total = _lane_tree(ss)
+    ms = (total / np.float32(d)).astype(np.float32)
+    rs = (np.float32(1.0) / np.sqrt((ms + np.float32(eps)).astype(np.float32))).astype(np.float32)
+    w1 = (np.float32(1.0) + np.asarray(weight, np.float32)).astype(np.float32)
+    normed = ((x2 * rs[:, None]).astype(np.float32) * w1).astype(np.float32)
+    return normed.reshape(lead + (d,)), rs.reshape(lead)
+
+
+def gemma_denorm_canonical(q, rs, weight):
+    w1 = (np.float32(1.0) + np.asarray(weight, np.float32)).astype(np.float32)
+    t = (np.asarray(q, np.float32) / w1).astype(np.float32)
+    return (t / np.asarray(rs, np.float32)[..., None]).astype(np.float32)

@@ -28,6 +28,8 @@ SYMBOLS = (
     "rqae_hip_quantize",
     "rqae_hip_decode",
     "rqae_hip_decode_values",
+    "rqae_hip_gemma_norm",
+    "rqae_hip_gemma_denorm_patch",
     "rqae_hip_kernel_info",
 )
 
@@ -64,6 +66,10 @@ def lib():
     L.rqae_hip_decode.restype = i
     L.rqae_hip_decode_values.argtypes = [vp, i, i, i, i, vp, i64, i, vp, vp, vp]
     L.rqae_hip_decode_values.restype = i
+    L.rqae_hip_gemma_norm.argtypes = [vp, i, vp, ctypes.c_float, i64, i, vp, vp, vp]
+    L.rqae_hip_gemma_norm.restype = i
+    L.rqae_hip_gemma_denorm_patch.argtypes = [vp, vp, vp, i64, i, i, i, vp, i, vp, vp]
+    L.rqae_hip_gemma_denorm_patch.restype = i
     L.rqae_hip_kernel_info.argtypes = [i, i, i, i, ctypes.c_char_p, sz]
     L.rqae_hip_kernel_info.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
@@ -197,6 +203,43 @@ def decode_values(packed, dims, cv3d: torch.Tensor, level_mask=None) -> torch.Te
                                           out.data_ptr(), _stream(cv3d.device))
     _check(rc, "rqae_hip_decode_values")
     return out
+
+
+def gemma_norm(hs: torch.Tensor, norm_weight: torch.Tensor, eps: float):
+    """hs [..., d] {f16,bf16,f32} -> (normed [..., d] f32, inv_rms [...] f32); rqae/llm.py:65-66."""
+    _require_cuda(hs, "hidden states")
+    if hs.dtype not in _X_DTYPES or not hs.is_contiguous():
+        raise RuntimeError("gemma_norm: hidden states must be contiguous f16/bf16/f32")
+    d = hs.shape[-1]
+    n = hs.numel() // d
+    w = norm_weight.detach().float().contiguous()
+    normed = torch.empty(hs.shape, dtype=torch.float32, device=hs.device)
+    rs = torch.empty(hs.shape[:-1], dtype=torch.float32, device=hs.device)
+    if n:
+        with torch.cuda.device(hs.device):
+            rc = lib().rqae_hip_gemma_norm(hs.data_ptr(), _X_DTYPES[hs.dtype], w.data_ptr(), float(eps), n, d,
+                                           normed.data_ptr(), rs.data_ptr(), _stream(hs.device))
+        _check(rc, "rqae_hip_gemma_norm")
+    return normed, rs
+
+
+def gemma_denorm_patch(q_out: torch.Tensor, norm_weight: torch.Tensor, inv_rms: torch.Tensor, hs_inout: torch.Tensor,
+                       skip_bos: bool, want_new: bool):
+    """Writes denorm(q_out) back into hs_inout [B,S,d] in place (BOS rows kept when skip_bos);
+    returns the fp32 `new` tensor when want_new.  rqae/llm.py:68-73, rqae/model.py:284-289."""
+    _require_cuda(q_out, "q_out")
+    B, S, d = hs_inout.shape
+    if hs_inout.dtype not in _X_DTYPES or not hs_inout.is_contiguous() or not q_out.is_contiguous():
+        raise RuntimeError("gemma_denorm_patch: tensors must be contiguous; hidden states f16/bf16/f32")
+    w = norm_weight.detach().float().contiguous()
+    new = torch.empty((B, S, d), dtype=torch.float32, device=q_out.device) if want_new else None
+    if B * S:
+        with torch.cuda.device(q_out.device):
+            rc = lib().rqae_hip_gemma_denorm_patch(q_out.data_ptr(), w.data_ptr(), inv_rms.data_ptr(), B * S, d, S,
+                                                   int(bool(skip_bos)), hs_inout.data_ptr(), _X_DTYPES[hs_inout.dtype],
+                                                   new.data_ptr() if want_new else None, _stream(q_out.device))
+        _check(rc, "rqae_hip_gemma_denorm_patch")
+    return new
 
 
 def kernel_info(d: int, c: int, K: int, L: int) -> str:

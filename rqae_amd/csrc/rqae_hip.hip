@@ -1514,6 +1514,88 @@ int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t
 #endif
 }
 
+
+// =============================================================== hook pre/post
+// The step either side of forward() in RQAE.hook (rqae/model.py:276-289) for a Gemma-2 LLM
+// (rqae/llm.py:65-73):  normed = (hs * rsqrt(mean(hs^2) + eps)) * (1 + w)   and afterwards
+// new = (q / (1 + w)) / rsqrt(mean(hs^2) + eps), new[:, 0] = hs[:, 0], written back in the LLM's dtype.
+// One wave per token.  Order of the mean: lane owns elements 4*(lane + 64*j) + {0..3}, j ascending,
+// fma chain of squares from +0 per lane, lanes summed by the tree of section 3, divided by d;
+// rs = 1 / sqrt(ms + eps) with IEEE sqrt and divide (oracle/oracle.py:gemma_norm_canonical restates it).
+__device__ __forceinline__ float wave_tree_sum(float v, int lane)
+{
+    float a[1] = {v}, fin[1];
+    ReduceScatter<1, 0, 1>::run(a, fin, lane);   // all singles: every lane ends with the full tree sum
+    return fin[0];
+}
+
+template <typename HT>
+__global__ void __launch_bounds__(256)
+gemma_norm_kernel(const HT *hs, const float *w, float eps, long long n_tokens, int d, float *normed, float *rs_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tokens) return;
+    const HT *row = hs + (size_t)tok * d;
+    float ss = 0.0f;
+    for (int e0 = 4 * lane; e0 < d; e0 += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u < d) { const float x = widen<HT>(row[e0 + u]); ss = fmaf(x, x, ss); }
+    }
+    const float total = wave_tree_sum(ss, lane);
+    const float ms = total / (float)d;
+    const float rs = 1.0f / __builtin_sqrtf(ms + eps);
+    if (lane == 0) rs_out[tok] = rs;
+    float *orow = normed + (size_t)tok * d;
+    for (int e0 = 4 * lane; e0 < d; e0 += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u < d) {
+                const float x = widen<HT>(row[e0 + u]);
+                const float t = x * rs;
+                orow[e0 + u] = t * (1.0f + w[e0 + u]);
+            }
+    }
+}
+
+template <typename HT>
+__device__ __forceinline__ HT narrow(float v);
+template <>
+__device__ __forceinline__ _Float16 narrow<_Float16>(float v) { return (_Float16)v; }
+template <>
+__device__ __forceinline__ float narrow<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ uint16_t narrow<uint16_t>(float v)   // round-to-nearest-even bf16 (as torch .to(bfloat16))
+{
+    return __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+
+template <typename HT>
+__global__ void __launch_bounds__(256)
+gemma_denorm_patch_kernel(const float *q, const float *w, const float *rs, long long n_tokens, int d, int seq_len,
+                          int skip_bos, HT *hs_inout, float *new_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tokens) return;
+    const bool bos = skip_bos && (tok % seq_len) == 0;
+    const float r = rs[tok];
+    const float *qrow = q + (size_t)tok * d;
+    HT *hrow = hs_inout + (size_t)tok * d;
+    float *nrow = new_out ? new_out + (size_t)tok * d : nullptr;
+    for (int e = lane; e < d; e += 64) {
+        float v;
+        if (bos) v = widen<HT>(hrow[e]);                       // q_out[:, 0] = hs[:, 0]  (model.py:285-286)
+        else {
+            const float t = qrow[e] / (1.0f + w[e]);           // rqae/llm.py:69
+            v = t / r;                                          // rqae/llm.py:70-72
+        }
+        if (nrow) nrow[e] = v;
+        if (!bos) hrow[e] = narrow<HT>(v);                      // output[0].data.copy_(q_out)  (model.py:289)
+    }
+}
+
 struct PackedView {
     const Header *hdr;
     const float *w_in, *w_out, *b_out, *b_in, *cb, *rec_p;
@@ -1680,6 +1762,47 @@ int rqae_hip_decode_values(const void *packed, int d, int c, int K, int L, const
                            int nq, const uint8_t *level_mask, float *out, void *stream)
 {
     return decode_common(packed, d, c, K, L, cv, false, 0, n_tokens, nq, level_mask, out, stream);
+}
+
+int rqae_hip_gemma_norm(const void *hs, int hs_dtype, const float *norm_weight, float eps, int64_t n_tokens, int d,
+                        float *normed, float *inv_rms, void *stream)
+{
+    if (!hs || !norm_weight || !normed || !inv_rms) return fail("gemma_norm: null pointer");
+    if (n_tokens < 0 || d < 1) return fail("gemma_norm: bad sizes");
+    if (hs_dtype < RQAE_X_F32 || hs_dtype > RQAE_X_F16) return fail("gemma_norm: bad hs_dtype %d", hs_dtype);
+    if (n_tokens == 0) return 0;
+    const long long nblk = (n_tokens + 3) / 4;
+    if (nblk > 0x7fffffffLL) return fail("gemma_norm: too many tokens for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hs_dtype == RQAE_X_F16)
+        hipLaunchKernelGGL(gemma_norm_kernel<_Float16>, dim3((unsigned)nblk), dim3(256), 0, s, (const _Float16 *)hs, norm_weight, eps, (long long)n_tokens, d, normed, inv_rms);
+    else if (hs_dtype == RQAE_X_BF16)
+        hipLaunchKernelGGL(gemma_norm_kernel<uint16_t>, dim3((unsigned)nblk), dim3(256), 0, s, (const uint16_t *)hs, norm_weight, eps, (long long)n_tokens, d, normed, inv_rms);
+    else
+        hipLaunchKernelGGL(gemma_norm_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, s, (const float *)hs, norm_weight, eps, (long long)n_tokens, d, normed, inv_rms);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rqae_hip_gemma_denorm_patch(const float *q_out, const float *norm_weight, const float *inv_rms, int64_t n_tokens,
+                                int d, int seq_len, int skip_bos, void *hs_inout, int hs_dtype, float *new_out,
+                                void *stream)
+{
+    if (!q_out || !norm_weight || !inv_rms || !hs_inout) return fail("gemma_denorm_patch: null pointer");
+    if (n_tokens < 0 || d < 1 || seq_len < 1) return fail("gemma_denorm_patch: bad sizes");
+    if (hs_dtype < RQAE_X_F32 || hs_dtype > RQAE_X_F16) return fail("gemma_denorm_patch: bad hs_dtype %d", hs_dtype);
+    if (n_tokens == 0) return 0;
+    const long long nblk = (n_tokens + 3) / 4;
+    if (nblk > 0x7fffffffLL) return fail("gemma_denorm_patch: too many tokens for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hs_dtype == RQAE_X_F16)
+        hipLaunchKernelGGL(gemma_denorm_patch_kernel<_Float16>, dim3((unsigned)nblk), dim3(256), 0, s, q_out, norm_weight, inv_rms, (long long)n_tokens, d, seq_len, skip_bos, (_Float16 *)hs_inout, new_out);
+    else if (hs_dtype == RQAE_X_BF16)
+        hipLaunchKernelGGL(gemma_denorm_patch_kernel<uint16_t>, dim3((unsigned)nblk), dim3(256), 0, s, q_out, norm_weight, inv_rms, (long long)n_tokens, d, seq_len, skip_bos, (uint16_t *)hs_inout, new_out);
+    else
+        hipLaunchKernelGGL(gemma_denorm_patch_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, s, q_out, norm_weight, inv_rms, (long long)n_tokens, d, seq_len, skip_bos, (float *)hs_inout, new_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 }  // extern "C"

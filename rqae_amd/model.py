@@ -367,7 +367,12 @@ class RQAE(nn.Module):
             llm = kwargs.pop("llm")
             assert hasattr(llm, "norm") and hasattr(llm, "denorm"), \
                 "RQAE hook requires norm and denorm from LLM"
-            return self.hook(norm=llm.norm, denorm=llm.denorm, **kwargs)
+            fused = kwargs.pop("fused", True)
+            generic = self.hook(norm=llm.norm, denorm=llm.denorm, **kwargs)
+            gemma = _gemma_final_norm(llm)
+            if gemma is not None and fused:
+                return self._gemma_hook(gemma, generic, **kwargs)
+            return generic
         if "norm" not in kwargs:
             raise ValueError("RQAE hook requires norm from LLM")
         if "denorm" not in kwargs:
@@ -393,3 +398,43 @@ class RQAE(nn.Module):
                 output[0].data.copy_(q_out)
 
         return hook_fn
+
+    def _gemma_hook(self, final_norm, generic_hook, **kwargs):
+        """hook() for an LLM whose norm/denorm are Gemma-2's (rqae/llm.py:65-73): the RMSNorm before
+        forward and the denorm + BOS skip + in-place write-back after it run as two HIP kernels
+        (include/rqae_hip.h: rqae_hip_gemma_norm / rqae_hip_gemma_denorm_patch) instead of ~12 torch
+        ops and their fp32 temporaries.  Same store() protocol and side effects as the generic hook."""
+        store = kwargs.get("store", None)
+        skip_bos = kwargs.get("skip_bos", True)
+        replace = kwargs.get("replace", True)
+        eps = float(getattr(final_norm, "eps", 1e-6))
+
+        def hook_fn(module, input, output):
+            hs_llm = output[0]
+            if (not hs_llm.is_cuda or not hs_llm.is_contiguous() or hs_llm.dim() != 3
+                    or hs_llm.dtype not in (torch.float16, torch.bfloat16, torch.float32)):
+                return generic_hook(module, input, output)   # same values, torch ops around forward()
+            if store is not None:
+                store("original", hs_llm.float())
+            normed, inv_rms = _native.gemma_norm(hs_llm, final_norm.weight, eps)
+            if store is not None:
+                store("normed", normed.detach().clone())
+            q_out, codes = self(normed)
+            if store is not None:
+                store("quantized", q_out.detach().clone())
+                store("indices", codes.detach().clone())
+            target = hs_llm if replace else hs_llm.clone()
+            new = _native.gemma_denorm_patch(q_out, final_norm.weight, inv_rms, target, skip_bos,
+                                             want_new=store is not None)
+            if store is not None:
+                store("new", new)
+
+        return hook_fn
+
+
+def _gemma_final_norm(llm):
+    """The RMSNorm module behind Gemma2.norm (rqae/llm.py:65-66: ``self.model.model.norm``), or None."""
+    norm = getattr(getattr(getattr(llm, "model", None), "model", None), "norm", None)
+    if norm is not None and hasattr(norm, "weight") and type(norm).__name__.lower().startswith("gemma"):
+        return norm
+    return None

@@ -334,3 +334,89 @@ def test_decode_full_size_and_uint16_codes():
     sel = np.arange(0, n, 1009)
     ref = oracle.decode(idx[0, sel].cpu().numpy(), w)
     assert np.array_equal(d64[0, sel].cpu().numpy(), ref)
+
+
+class Gemma2RMSNorm(torch.nn.Module):
+    """HF Gemma2RMSNorm, the module behind Gemma2.norm (rqae/llm.py:65-66)."""
+
+    def __init__(self, weight, eps=1e-6):
+        super().__init__()
+        self.weight = torch.nn.Parameter(weight)
+        self.eps = eps
+
+    def forward(self, x):
+        out = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + self.eps)
+        return (out * (1.0 + self.weight.float())).type_as(x)
+
+
+class FakeGemma2LLM:
+    """Shaped like rqae/llm.py:Gemma2: .model.model.norm plus norm()/denorm()."""
+
+    def __init__(self, weight):
+        inner = torch.nn.Module()
+        inner.norm = Gemma2RMSNorm(weight)
+        outer = torch.nn.Module()
+        outer.model = inner
+        self.model = outer
+
+    def norm(self, hidden_states):
+        return self.model.model.norm(hidden_states)
+
+    def denorm(self, hidden_states, original_hidden_states):
+        hidden_states = hidden_states / (1.0 + self.model.model.norm.weight.float())
+        return hidden_states.float() / torch.rsqrt(
+            original_hidden_states.float().pow(2).mean(-1, keepdim=True) + 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_gemma_hook(dtype):
+    """norm before / denorm + BOS skip + in-place write-back after forward as HIP kernels.
+    Bit-exact against the oracle's restatement; against the torch ops of the generic hook to rounding."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    B, S, d = 3, 40, cfg["dim"]
+    rng = np.random.Generator(np.random.PCG64(6))
+    nw = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    llm = FakeGemma2LLM(torch.from_numpy(nw).to(DEV))
+    hs0 = (torch.from_numpy(synth.activations(77, B * S, d)) * 3.0).to(dtype).view(B, S, d).to(DEV)
+
+    def run(fused):
+        hs = hs0.clone()
+        st = {}
+        fn = m.hook(llm=llm, store=lambda k, v: st.update({k: v}), fused=fused)
+        with torch.inference_mode():
+            fn(None, None, (hs,))
+        torch.cuda.synchronize()
+        return hs, st
+
+    hs_f, st_f = run(True)
+    hs_g, st_g = run(False)
+    assert set(st_f) == set(st_g) == {"original", "normed", "quantized", "indices", "new"}
+    # --- oracle restatement: bit for bit
+    hs_np = hs0.float().cpu().numpy()
+    normed_o, rs_o = oracle.gemma_norm_canonical(hs_np, nw)
+    assert np.array_equal(st_f["normed"].cpu().numpy(), normed_o)
+    q_o, idx_o = oracle.forward(normed_o, w)
+    assert np.array_equal(st_f["indices"].cpu().numpy(), idx_o)
+    assert np.array_equal(st_f["quantized"].cpu().numpy(), q_o)
+    new_o = oracle.gemma_denorm_canonical(q_o, rs_o, nw)
+    new_o[:, 0] = hs_np[:, 0]
+    assert np.array_equal(st_f["new"].cpu().numpy(), new_o)
+    assert torch.equal(hs_f, torch.from_numpy(new_o).to(dtype).to(DEV))          # patched in place, LLM dtype
+    assert torch.equal(hs_f[:, 0], hs0[:, 0])                                     # BOS rows untouched
+    # --- the generic (torch-op) hook: same thing to rounding
+    assert rel_err(st_f["normed"].cpu().numpy(), st_g["normed"].cpu().numpy()) < 1e-6
+    same = (st_f["indices"] == st_g["indices"]).all(-1).float().mean().item()
+    assert same >= 0.98                                                           # normed differs in the last bit
+    ok = (st_f["indices"] == st_g["indices"]).all(-1)
+    assert rel_err(st_f["new"][ok].cpu().numpy(), st_g["new"][ok].cpu().numpy()) < 1e-5
+    # --- without a store nothing is cloned, the patch still happens; replace=False leaves hs alone
+    hs2 = hs0.clone()
+    with torch.inference_mode():
+        m.hook(llm=llm)(None, None, (hs2,))
+    assert torch.equal(hs2, hs_f)
+    hs3 = hs0.clone()
+    with torch.inference_mode():
+        m.hook(llm=llm, replace=False)(None, None, (hs3,))
+    assert torch.equal(hs3, hs0)

@@ -120,3 +120,18 @@ def test_empty_and_single_token():
     assert q.shape == (0, cfg["dim"]) and idx.shape == (0, 4)
     q, idx = oracle.forward(np.zeros((1, cfg["dim"]), np.float32), w)
     assert np.isfinite(q).all()
+
+
+def test_canonical_gemma_norm_against_reference_capture():
+    """The hook pre/post restatement (oracle.gemma_*_canonical) against the reference's hook capture."""
+    h = load_golden("hook_c2")
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(h["meta"]["seed_w"], cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    normed, rs = oracle.gemma_norm_canonical(h["hs"], h["norm_weight"])
+    assert rel_err(normed, h["normed"]) < 1e-6
+    q, idx = oracle.forward(normed, w)
+    assert np.array_equal(idx, h["indices"].astype(np.int64))
+    new = oracle.gemma_denorm_canonical(q, rs, h["norm_weight"])
+    new[:, 0] = h["hs"][:, 0].astype(np.float32)
+    assert rel_err(new, h["new"]) < 1e-5
+    assert (new.astype(np.float16) != h["patched"]).mean() < 1e-3      # fp16 write-back: at most a rare last-bit flip

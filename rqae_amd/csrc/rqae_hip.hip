@@ -363,6 +363,7 @@ struct EncParams {
     int kch;  // codebook rows staged in LDS per chunk (multiple of 64, or >= K)
     int aligned16;  // x and q_out 16-byte aligned: full tiles may use vector loads/stores
     int ablate;  // RQAE_HIP_ABLATE bits: timing experiments only, results are wrong when != 0
+    int tl_lds_floats;  // RQAE_TIMELINE builds: float offset of the stamp buffer in LDS
 };
 
 // P  : elements per lane per slice (dp = 256*P)      C : codebook_dim
@@ -732,6 +733,22 @@ __device__ __forceinline__ unsigned lds_addr_of(const float *p)
 // lane = element (or codebook row), the four accumulator registers = four tokens.  K = 1 per
 // instruction, so a chain of c instructions is the k-ordered fmaf chain of the contract, bit for bit
 // (checked on hardware by the parity tests), with no padding of c.
+// Timeline probe (build with -DRQAE_TIMELINE, scratch/timeline.sh; never part of the shipped library):
+// every wave of 4 sample workgroups stamps s_memtime at its phase boundaries.
+#ifdef RQAE_TIMELINE
+__device__ long long g_timeline[4][8][64];
+#define TL_STAMP()                                                        \
+    do {                                                                  \
+        if (tl_on) {                                                      \
+            const long long tl_t = __builtin_readcyclecounter();          \
+            if (lane == 0 && tl_n < 64) tl_buf[wave * 64 + tl_n] = tl_t;  \
+        }                                                                 \
+        ++tl_n;                                                           \
+    } while (0)
+#else
+#define TL_STAMP() do { } while (0)
+#endif
+
 template <int P, int C, bool RECON, bool MFMA>
 __global__ void __launch_bounds__(512, 2)
 rqae_encode_lds_kernel(const EncParams p)
@@ -753,6 +770,13 @@ rqae_encode_lds_kernel(const EncParams p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slice = wave & 3;
     const int half = wave >> 2;
+#ifdef RQAE_TIMELINE
+    const bool tl_on = (blockIdx.x % 4096) == 2053 && blockIdx.x / 4096 < 4;
+    int tl_n = 0;
+    long long *tl_buf = reinterpret_cast<long long *>(smem + p.tl_lds_floats);
+    if (tl_on) tl_buf[wave * 64 + lane] = 0;
+    TL_STAMP();
+#endif
     const long long tok0 = (long long)blockIdx.x * TG;
     const long long tokw = tok0 + half * TPW;
 
@@ -796,6 +820,10 @@ rqae_encode_lds_kernel(const EncParams p)
 #pragma unroll
             for (int pr = 0; pr < NPAIR; ++pr) r2[i][pr] = (f2){xt[i][2 * pr], xt[i][2 * pr + 1]};
     }
+#ifdef RQAE_TIMELINE
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory");   // (also waits for record 0: stamp 1 = x + record landed)
+#endif
+    TL_STAMP();
     // One pass over this wave's registers.  DO_OUT: apply a level (lin_out, r -= y, out += y).
     // DO_IN: project onto the next level (lin_in partials -> 64-lane tree -> LDS).
     // FIRST: the reconstruction starts as 0 + y (rqae/model.py:201,224) -- no zeroed registers kept.
@@ -1012,12 +1040,18 @@ rqae_encode_lds_kernel(const EncParams p)
     // ---- level 0 projection
     float bin_own = bias_of(0);
     slot_end();                                           // record 0 + codebook landed
+    TL_STAMP();
     pass(F{}, T{}, F{});
     land_bias(bin_own);
+    TL_STAMP();
     __syncthreads();                                      // `part` published, wts free
+    TL_STAMP();
     if (!(p.ablate & 1)) issue_dma(1);
+    TL_STAMP();
     if (!(p.ablate & 2)) quantise(0, bin_own);
+    TL_STAMP();
     slot_end();                                           // cvs published, record 1 landed
+    TL_STAMP();
 
     if (p.levels > 1) {                                   // level 0 applied, level 1 projected
         bin_own = bias_of(1);
@@ -1027,10 +1061,15 @@ rqae_encode_lds_kernel(const EncParams p)
             stage_rows<C>(cbl, p.cb + (size_t)(shared_cb ? 0 : 1) * p.K * C, rows);
         }
         land_bias(bin_own);
+        TL_STAMP();
         __syncthreads();
+        TL_STAMP();
         if (!(p.ablate & 1)) issue_dma(2);
+        TL_STAMP();
         if (!(p.ablate & 2)) quantise(1, bin_own);
+        TL_STAMP();
         slot_end();
+        TL_STAMP();
     }
     for (int l = 1; l + 1 < p.levels; ++l) {
         bin_own = bias_of(l + 1);
@@ -1040,13 +1079,24 @@ rqae_encode_lds_kernel(const EncParams p)
             stage_rows<C>(cbl, p.cb + (size_t)(shared_cb ? 0 : l + 1) * p.K * C, rows);
         }
         land_bias(bin_own);
+        TL_STAMP();
         __syncthreads();
+        TL_STAMP();
         if (!(p.ablate & 1)) issue_dma(l + 2);
+        TL_STAMP();
         if (!(p.ablate & 2)) quantise(l + 1, bin_own);
+        TL_STAMP();
         slot_end();
+        TL_STAMP();
     }
     if (p.levels > 1) pass(T{}, F{}, F{});                // apply the last level
     else pass(T{}, F{}, T{});
+    TL_STAMP();
+#ifdef RQAE_TIMELINE
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory");
+    TL_STAMP();
+    if (tl_on) g_timeline[blockIdx.x / 4096][wave][lane] = tl_buf[wave * 64 + lane];
+#endif
 
     if constexpr (RECON) {
         if (!full_tile) {   // ragged tile: predicated stores after the loop (full tiles stored inside the last pass)
@@ -1083,7 +1133,12 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
         q.ablate = ab ? atoi(ab) : 0;
     }
     const int rows = kch < p.K ? kch : p.K;
+#ifdef RQAE_TIMELINE
+    q.tl_lds_floats = (int)((fixed / sizeof(float) + cb_lds_floats(C, rows) + 3) & ~(size_t)3);
+    const size_t lds = sizeof(float) * (size_t)q.tl_lds_floats + 8 * 64 * sizeof(long long);
+#else
     const size_t lds = fixed + sizeof(float) * (size_t)cb_lds_floats(C, rows);
+#endif
     const long long nblk = (p.n_tokens + TG - 1) / TG;
     if (nblk > 0x7fffffffLL) return fail("encode: too many tokens for one launch");
     auto go = [&](auto kern) -> int {
@@ -1651,6 +1706,13 @@ int decode_common(const void *packed, int d, int c, int K, int L, const void *sr
 }  // namespace
 
 // =================================================================== C ABI
+#ifdef RQAE_TIMELINE
+extern "C" int rqae_hip_debug_timeline(long long *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_timeline), sizeof(long long) * 4 * 8 * 64);
+}
+#endif
+
 extern "C" {
 
 int rqae_hip_abi_version(void) { return RQAE_HIP_ABI_VERSION; }

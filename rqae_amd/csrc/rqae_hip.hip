@@ -67,9 +67,15 @@ struct Header {
     int magic, d, c, K, L, dp, shared_cb, pad;
 };
 
+// quads (float4) per lane per slice of a pass record: see make_layout
+constexpr int quads_of(int floats) { return (floats + 3) / 4; }
+constexpr int rec_out_quads(int P, int C) { return quads_of(P * (C + 1)); }   // {w_out[0..C-1], b_out} per element
+constexpr int rec_in_quads(int P, int C) { return quads_of(P * C); }          // {w_in[0..C-1]} per element
+constexpr int rec_quads(int P, int C) { return rec_out_quads(P, C) + rec_in_quads(P, C); }
+
 struct Layout {
     size_t w_in, w_out, b_out, b_in, cb, rec_p, total;
-    int dp, qi;  // qi: float4s per lane per element step in a pass record
+    int dp, nq;  // nq: float4s per lane per slice in a pass record
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -84,12 +90,14 @@ Layout make_layout(int d, int c, int K, int L)
     lo.b_out = off; off += align256(sizeof(float) * (size_t)L * lo.dp);
     lo.b_in = off;  off += align256(sizeof(float) * (size_t)L * c);
     lo.cb = off;    off += align256(sizeof(float) * (size_t)L * K * c);
-    // Pass records for the LDS-staged kernel.  Pass pl (0..L) applies level pl-1 and projects
-    // onto level pl; its weights are one contiguous block, cut into 1-KiB pieces that LDS-DMA
-    // copies verbatim:  rec_p[pl][slice][i][quad][lane][4] with the lane's 2c+1 floats
-    //   { w_out[pl-1][el][0..c-1], b_out[pl-1][el], w_in[pl][0..c-1][el] },  el = slice*64P + 64i + lane
-    lo.qi = (2 * c + 1 + 3) / 4;
-    lo.rec_p = off; off += align256(sizeof(float) * (size_t)(L + 1) * NSLICE * (lo.dp / 256) * lo.qi * 256);
+    // Pass records for the LDS-staged kernels.  Pass pl (0..L) applies level pl-1 and projects onto
+    // level pl; its weights are one contiguous block, cut into 1-KiB pieces that LDS-DMA copies
+    // verbatim:  rec_p[pl][slice][quad][lane][4].  A lane's floats are two packed streams over its
+    // P element steps (el = elem_of(P, slice, i, lane)):
+    //   quads [0, QOUT):    n = i*(c+1) + k   { w_out[pl-1][el][0..c-1], b_out[pl-1][el] }
+    //   quads [QOUT, NQ):   n = i*c + j       { w_in[pl][j][el] }
+    lo.nq = rec_quads(lo.dp / 256, c);
+    lo.rec_p = off; off += align256(sizeof(float) * (size_t)(L + 1) * NSLICE * lo.nq * 256);
     lo.total = off;
     return lo;
 }
@@ -113,26 +121,31 @@ bool shape_ok(int d, int c, int K, int L)
 }
 
 // Fill the pass records (see make_layout).  One thread per float.
-__global__ void pack_records_kernel(Header h, int qi, float *rec_p, const float *w_in, const float *w_out,
+__global__ void pack_records_kernel(Header h, int nq, int qout, float *rec_p, const float *w_in, const float *w_out,
                                     const float *b_out)
 {
     const int P = h.dp / 256;
-    const size_t total = (size_t)(h.L + 1) * NSLICE * P * qi * 256;
+    const size_t total = (size_t)(h.L + 1) * NSLICE * nq * 256;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += stride) {
         const int e4 = (int)(u & 3), lane = (int)((u >> 2) & 63);
-        size_t rest = u >> 8;                      // ((pl*4 + slice)*P + i)*qi + quad
-        const int quad = (int)(rest % qi); rest /= qi;
-        const int i = (int)(rest % P); rest /= P;
+        size_t rest = u >> 8;                      // (pl*4 + slice)*nq + quad
+        const int quad = (int)(rest % nq); rest /= nq;
         const int slice = (int)(rest & 3);
         const size_t pl = rest >> 2;
-        const int n = quad * 4 + e4;
-        const int el = elem_of(P, slice, i, lane);
         float val = 0.0f;
-        if (el < h.d) {
-            if (n < h.c) { if (pl >= 1) val = w_out[((pl - 1) * h.d + el) * h.c + n]; }
-            else if (n == h.c) { if (pl >= 1) val = b_out[(pl - 1) * h.d + el]; }
-            else if (n <= 2 * h.c) { if (pl < (size_t)h.L) val = w_in[(pl * h.c + (n - h.c - 1)) * h.d + el]; }
+        if (quad < qout) {                         // lin_out stream of level pl-1
+            const int n = quad * 4 + e4, i = n / (h.c + 1), k = n % (h.c + 1);
+            if (i < P && pl >= 1) {
+                const int el = elem_of(P, slice, i, lane);
+                if (el < h.d) val = k < h.c ? w_out[((pl - 1) * h.d + el) * h.c + k] : b_out[(pl - 1) * h.d + el];
+            }
+        } else {                                   // lin_in stream of level pl
+            const int n = (quad - qout) * 4 + e4, i = n / h.c, j = n % h.c;
+            if (i < P && pl < (size_t)h.L) {
+                const int el = elem_of(P, slice, i, lane);
+                if (el < h.d) val = w_in[(pl * h.c + j) * h.d + el];
+            }
         }
         rec_p[u] = val;
     }
@@ -749,19 +762,34 @@ __device__ long long g_timeline[4][8][64];
 #define TL_STAMP() do { } while (0)
 #endif
 
+// Lane-private weight streams of a pass record: the lane's floats [i*W, (i+1)*W) for element step i,
+// stored as quads q at base[q * 64] (f4 units).  All indices are compile-time after unrolling.
+constexpr int last_quad_of_step(int i, int W) { return ((i + 1) * W - 1) / 4; }
+__device__ __forceinline__ float f4_get(const f4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+// acc += a * broadcast(component c of quad) as ONE v_pk_fma_f32 whose op_sel picks the component out of the
+// quad's aligned register pair.  Written in asm because with four users per weight hipcc materialises the
+// splat (two v_mov per weight, +40 VGPRs of pressure and spills) instead of folding it into op_sel.
+// c must be a constant after unrolling.
+__device__ __forceinline__ void pk_fma_bcast(f2 &acc, f2 a, const f4 &quad, int c)
+{
+    const f2 pair = c < 2 ? __builtin_shufflevector(quad, quad, 0, 1) : __builtin_shufflevector(quad, quad, 2, 3);
+    if ((c & 1) == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(pair));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(a), "v"(pair));
+}
+
 template <int P, int C, bool RECON, bool MFMA>
 __global__ void __launch_bounds__(512, 2)
 rqae_encode_lds_kernel(const EncParams p)
 {
     constexpr int TPW = 8, NW = 8, TG = 16, TQ = 2, JW = 8, NG = 2, NPAIR = 4;
     static_assert(C <= 8, "quantise phase uses 8 lanes per token");
-    constexpr int QI = (2 * C + 1 + 3) / 4;
-    constexpr int NPIECE = NSLICE * P * QI;     // 1-KiB pieces in one pass record
+    constexpr int QOUT = rec_out_quads(P, C), QIN = rec_in_quads(P, C), NQ = QOUT + QIN;
+    constexpr int NPIECE = NSLICE * NQ;         // 1-KiB pieces in one pass record
     constexpr int WFLOATS = NPIECE * 256;
     constexpr int dp = 256 * P;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wts = smem;                       // [slice][i][quad][lane][4]
+    float *wts = smem;                       // [slice][quad][lane][4]
     float *part = wts + WFLOATS;             // [TG][C][NSLICE]: the 4 slice partials of one (token, j) are contiguous
     float *cvs = part + NSLICE * TG * C;     // [C][TG]  (token pairs contiguous)
     float *cbl = cvs + ((TG * C + 3) & ~3);  // [kch][C]
@@ -790,13 +818,27 @@ rqae_encode_lds_kernel(const EncParams p)
     const bool act = tq < TQ && jj < C;
 
     const unsigned wts_addr = lds_addr_of(wts);
-    auto issue_dma = [&](int pl) {           // the record of pass pl -> wts (all 8 waves share the work)
-        const float *src = p.rec_p + (size_t)pl * WFLOATS;   // uniform
-        for (int pc = wave; pc < NPIECE; pc += NW) dma_pieces<1>(src + pc * 256, wts_addr + pc * 1024, lane * 16);
+    // The record of pass pl goes to `wts` in 1-KiB pieces; the 8 waves share the pieces.  A wave's pieces are
+    // issued ONE AT A TIME from inside its quantise phase (dma_step): a burst of ~13 global_load_lds per wave
+    // blocks on the TA's address queue for ~1 800 cycles per level (measured, profiles/r01_timeline_*).
+    int dma_next = NPIECE;                   // next piece of this wave (>= NPIECE: nothing to issue)
+    const float *dma_src = p.rec_p;
+    auto dma_begin = [&](int pl, int first_piece) {
+        dma_src = p.rec_p + (size_t)pl * WFLOATS;
+        dma_next = first_piece + wave;
     };
+    auto dma_step = [&]() __attribute__((always_inline)) {
+        if (dma_next < NPIECE) {
+            dma_pieces<1>(dma_src + dma_next * 256, wts_addr + dma_next * 1024, lane * 16);
+            dma_next += NW;
+        }
+    };
+    auto dma_flush = [&]() { while (dma_next < NPIECE) dma_step(); };
 
-    issue_dma(0);
-    {
+    {   // record 0: only its lin_in part is read
+        for (int s = 0; s < NSLICE; ++s)
+            for (int q = QOUT + wave; q < NQ; q += NW)
+                dma_pieces<1>(p.rec_p + (s * NQ + q) * 256, wts_addr + (s * NQ + q) * 1024, lane * 16);
         const int rows = p.kch < p.K ? p.kch : p.K;
         stage_rows<C>(cbl, p.cb, rows);
     }
@@ -824,58 +866,52 @@ rqae_encode_lds_kernel(const EncParams p)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory");   // (also waits for record 0: stamp 1 = x + record landed)
 #endif
     TL_STAMP();
-    // One pass over this wave's registers.  DO_OUT: apply a level (lin_out, r -= y, out += y).
-    // DO_IN: project onto the next level (lin_in partials -> 64-lane tree -> LDS).
-    // FIRST: the reconstruction starts as 0 + y (rqae/model.py:201,224) -- no zeroed registers kept.
-    auto pass = [&](auto do_out_t, auto do_in_t, auto first_t) {
-        constexpr bool DO_OUT = decltype(do_out_t)::value, DO_IN = decltype(do_in_t)::value;
-        constexpr bool FIRST = decltype(first_t)::value;
-        const f4 *wl = reinterpret_cast<const f4 *>(wts) + (size_t)slice * P * QI * 64 + lane;
+
+    const f4 *wl = reinterpret_cast<const f4 *>(wts) + (size_t)slice * NQ * 64 + lane;
+
+    // ---- sweep 1 of a pass: apply a level.  y = lin_out(cv); r -= y; out += y, for the wave's 8 tokens per
+    // element step, so every weight quad is read from LDS once per wave (read per token group, LDS bandwidth
+    // bounds the pass).  FIRST: the reconstruction starts as 0 + y (rqae/model.py:201,224).  LAST: the
+    // reconstruction is final -- store it from inside the sweep.
+    auto pass_out = [&](auto first_t, auto last_t) {
+        constexpr bool FIRST = decltype(first_t)::value, LAST = decltype(last_t)::value;
+        constexpr int W = C + 1;
+        f2 cv2[NG][2][C];     // wave-uniform straight-through values as SGPR pairs, not 40 VGPRs
+        float a_cv[NG][C];    // MFMA A operands: lane i (0..3) holds the value of token 4g+i
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            f2 cv2[2][C];
-            float a_cv[C];   // MFMA A operands: lane i (0..3) holds the value of token 4g+i
-            if constexpr (DO_OUT) {
-                if constexpr (MFMA) {
+            if constexpr (MFMA) {
 #pragma unroll
-                    for (int k = 0; k < C; ++k) a_cv[k] = cvs[k * TG + half * TPW + 4 * g + (lane & 3)];
-                } else {
+                for (int k = 0; k < C; ++k) a_cv[g][k] = cvs[k * TG + half * TPW + 4 * g + (lane & 3)];
+            } else {
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr)
+                for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-                        for (int k = 0; k < C; ++k) {
-                            // wave-uniform values: keep them in SGPR pairs, not in 20 VGPRs
-                            const f2 v = *reinterpret_cast<const f2 *>(cvs + k * TG + half * TPW + 4 * g + 2 * pr);
-                            cv2[pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
-                        }
-                }
+                    for (int k = 0; k < C; ++k) {
+                        const f2 v = *reinterpret_cast<const f2 *>(cvs + k * TG + half * TPW + 4 * g + 2 * pr);
+                        cv2[g][pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
+                    }
             }
-            f2 acc2[2][C];
+        }
+        f4 wq[QOUT];          // SSA values: each quad lives from its read (one step ahead) to its last use
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr)
+        for (int q = 0; q < QOUT; ++q)
+            if (q <= last_quad_of_step(0, W)) wq[q] = wl[q * 64];
 #pragma unroll
-                for (int j = 0; j < C; ++j) acc2[pr][j] = splat2(0.0f);
-            // weights of element step i+1 are fetched from LDS while step i computes
-            f4 wq[2][QI];
+        for (int i = 0; i < P; ++i) {
 #pragma unroll
-            for (int qd = 0; qd < QI; ++qd) wq[0][qd] = wl[qd * 64];
+            for (int q = 0; q < QOUT; ++q)
+                if (i + 1 < P && q > last_quad_of_step(i, W) && q <= last_quad_of_step(i + 1, W)) wq[q] = wl[q * 64];
+            float w[W];
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                if (i + 1 < P) {
+            for (int k = 0; k < W; ++k) w[k] = f4_get(wq[(i * W + k) / 4], (i * W + k) % 4);
 #pragma unroll
-                    for (int qd = 0; qd < QI; ++qd) wq[(i + 1) & 1][qd] = wl[((i + 1) * QI + qd) * 64];
-                }
-                float w[QI * 4];
-#pragma unroll
-                for (int qd = 0; qd < QI; ++qd) {
-                    const f4 v = wq[i & 1][qd];
-                    w[4 * qd] = v.x; w[4 * qd + 1] = v.y; w[4 * qd + 2] = v.z; w[4 * qd + 3] = v.w;
-                }
+            for (int g = 0; g < NG; ++g) {
                 f2 ym[2];
-                if constexpr (DO_OUT && MFMA) {
+                if constexpr (MFMA) {
                     f4 y4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int k = 0; k < C; ++k) y4 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cv[k], w[k], y4, 4, 0, 0);
+                    for (int k = 0; k < C; ++k) y4 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cv[g][k], w[k], y4, 4, 0, 0);
                     y4 = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, w[C], y4, 4, 0, 0);   // + bias, one rounding
                     ym[0] = (f2){y4.x, y4.y};
                     ym[1] = (f2){y4.z, y4.w};
@@ -883,52 +919,79 @@ rqae_encode_lds_kernel(const EncParams p)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     f2 &rr = r2[i][2 * g + pr];
-                    if constexpr (DO_OUT) {
-                        f2 y;
-                        if constexpr (MFMA) {
-                            y = ym[pr];
-                        } else {
-                            y = splat2(0.0f);
+                    f2 y;
+                    if constexpr (MFMA) {
+                        y = ym[pr];
+                    } else {
+                        y = splat2(0.0f);
 #pragma unroll
-                            for (int k = 0; k < C; ++k) y = fma2(cv2[pr][k], splat2(w[k]), y);
-                            y = y + splat2(w[C]);
-                        }
-                        rr = rr - y;
-                        if constexpr (RECON) {
-                            if constexpr (FIRST) out2[i][2 * g + pr] = splat2(0.0f) + y;
-                            else  // one opaque instruction: written as C++ the allocator needs ~60 more VGPRs and spills
-                                asm("v_pk_add_f32 %0, %0, %1" : "+v"(out2[i][2 * g + pr]) : "v"(y));
-                            if constexpr (!DO_IN) {
-                                // last level: this element pair is final -- store it now, under the rest of the pass
-                                if (full_tile) {
-                                    const int t0 = 4 * g + 2 * pr;
-                                    float *o0 = p.q_out + (size_t)(tokw + t0) * p.d;
-                                    store_run_ending_at<P>(o0, slice, lane, i, [&](int k) { return out2[k][2 * g + pr].x; });
-                                    store_run_ending_at<P>(o0 + p.d, slice, lane, i, [&](int k) { return out2[k][2 * g + pr].y; });
-                                }
+                        for (int k = 0; k < C; ++k) y = fma2(cv2[g][pr][k], splat2(w[k]), y);
+                        y = y + splat2(w[C]);
+                    }
+                    rr = rr - y;
+                    if constexpr (RECON) {
+                        if constexpr (FIRST) out2[i][2 * g + pr] = splat2(0.0f) + y;
+                        else if constexpr (MFMA)   // y is an MFMA result: stay behind `rr - y`, whose hazard nops hipcc places
+                            asm("v_pk_add_f32 %0, %0, %2" : "+v"(out2[i][2 * g + pr]), "+v"(rr) : "v"(y));
+                        else  // one opaque instruction: written as C++ the allocator needs ~60 more VGPRs and spills
+                            asm("v_pk_add_f32 %0, %0, %1" : "+v"(out2[i][2 * g + pr]) : "v"(y));
+                        if constexpr (LAST) {
+                            if (full_tile) {
+                                const int t0 = 4 * g + 2 * pr;
+                                float *o0 = p.q_out + (size_t)(tokw + t0) * p.d;
+                                store_run_ending_at<P>(o0, slice, lane, i, [&](int k) { return out2[k][2 * g + pr].x; });
+                                store_run_ending_at<P>(o0 + p.d, slice, lane, i, [&](int k) { return out2[k][2 * g + pr].y; });
                             }
                         }
                     }
-                    if constexpr (DO_IN) {
-#pragma unroll
-                        for (int j = 0; j < C; ++j) acc2[pr][j] = fma2(rr, splat2(w[C + 1 + j]), acc2[pr][j]);
-                    }
                 }
             }
-            if constexpr (DO_IN) {
-                float vals[4 * C];
+        }
+    };
+
+    // ---- sweep 2 of a pass: project the residual onto the next level (lin_in partials over this wave's
+    // quarter of d -> 64-lane tree -> LDS), again with one LDS read of each weight quad for all 8 tokens.
+    auto pass_in = [&]() {
+        constexpr int W = C;
+        const f4 *wi = wl + QOUT * 64;
+        f2 acc2[NG][2][C];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int j = 0; j < C; ++j) acc2[g][pr][j] = splat2(0.0f);
+        f4 wq[QIN];
+#pragma unroll
+        for (int q = 0; q < QIN; ++q)
+            if (q <= last_quad_of_step(0, W)) wq[q] = wi[q * 64];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+#pragma unroll
+            for (int q = 0; q < QIN; ++q)
+                if (i + 1 < P && q > last_quad_of_step(i, W) && q <= last_quad_of_step(i + 1, W)) wq[q] = wi[q * 64];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-                    for (int j = 0; j < C; ++j) {
-                        vals[(2 * pr) * C + j] = acc2[pr][j].x;
-                        vals[(2 * pr + 1) * C + j] = acc2[pr][j].y;
-                    }
-                float fin[1];
-                ReduceScatter<4 * C, 0, 1>::run(vals, fin, lane);
-                const int v0 = rs_value_of_lane(lane);
-                if (v0 < 4 * C) part[((half * TPW + 4 * g) * C + v0) * NSLICE + slice] = fin[0];
-            }
+                    for (int j = 0; j < C; ++j)
+                        pk_fma_bcast(acc2[g][pr][j], r2[i][2 * g + pr], wq[(i * W + j) / 4], (i * W + j) % 4);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float vals[4 * C];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    vals[(2 * pr) * C + j] = acc2[g][pr][j].x;
+                    vals[(2 * pr + 1) * C + j] = acc2[g][pr][j].y;
+                }
+            float fin[1];
+            ReduceScatter<4 * C, 0, 1>::run(vals, fin, lane);
+            const int v0 = rs_value_of_lane(lane);
+            if (v0 < 4 * C) part[((half * TPW + 4 * g) * C + v0) * NSLICE + slice] = fin[0];
         }
     };
     using T = std::true_type;
@@ -968,7 +1031,8 @@ rqae_encode_lds_kernel(const EncParams p)
                 stage_rows<C>(cbl, p.cb + ((size_t)(shared_cb ? 0 : l) * p.K + row_base) * C, rows);
                 __syncthreads();
             }
-            auto scan_block = [&](int r0, bool in) {
+            auto scan_block = [&](int r0, bool in) __attribute__((always_inline)) {
+                dma_step();   // one piece of the next record per 64 codebook rows
                 const int row = r0 + lane;
                 float cbv[C];
                 load_row<C>(cbv, cbl, in ? row : 0, rows);
@@ -998,6 +1062,7 @@ rqae_encode_lds_kernel(const EncParams p)
             for (int r0 = full4; r0 < full; r0 += 64) scan_block(r0, true);
             if (full < rows) scan_block(full, full + lane < rows);
         }
+        dma_flush();   // small codebooks: fewer scan blocks than pieces
         // wave-wide first maximum per token: max by reduce-scatter, then the lowest row among its holders
         float mx[1];
         ReduceScatter<TQ, 0, 1, 1>::run(best, mx, lane);
@@ -1036,61 +1101,51 @@ rqae_encode_lds_kernel(const EncParams p)
     auto bias_of = [&](int l) { return act ? p.b_in[l * C + jj] : 0.0f; };
     auto land_bias = [&](float &b) { asm volatile("" : "+v"(b)); };
     auto slot_end = [&]() { dma_wait_all(); __syncthreads(); };
+    auto restage = [&](int l) {   // per-level codebooks: level l's rows replace level l-1's
+        if (!stage_once) {
+            const int rows = p.kch < p.K ? p.kch : p.K;
+            stage_rows<C>(cbl, p.cb + (size_t)(shared_cb ? 0 : l) * p.K * C, rows);
+        }
+    };
+    // one level slot: [barrier: partials published, wts free] quantise(l) with record l+1 streaming in
+    auto slot = [&](int l, float bin_own) __attribute__((always_inline)) {
+        land_bias(bin_own);
+        TL_STAMP();
+        __syncthreads();
+        TL_STAMP();
+        if (!(p.ablate & 1)) dma_begin(l + 1, 0);
+        if (!(p.ablate & 2)) quantise(l, bin_own);
+        else dma_flush();
+        TL_STAMP();
+        slot_end();                                       // cvs published, record l+1 landed
+        TL_STAMP();
+    };
 
     // ---- level 0 projection
     float bin_own = bias_of(0);
     slot_end();                                           // record 0 + codebook landed
     TL_STAMP();
-    pass(F{}, T{}, F{});
-    land_bias(bin_own);
-    TL_STAMP();
-    __syncthreads();                                      // `part` published, wts free
-    TL_STAMP();
-    if (!(p.ablate & 1)) issue_dma(1);
-    TL_STAMP();
-    if (!(p.ablate & 2)) quantise(0, bin_own);
-    TL_STAMP();
-    slot_end();                                           // cvs published, record 1 landed
-    TL_STAMP();
+    pass_in();
+    slot(0, bin_own);
 
     if (p.levels > 1) {                                   // level 0 applied, level 1 projected
         bin_own = bias_of(1);
-        pass(T{}, T{}, T{});
-        if (!stage_once) {
-            const int rows = p.kch < p.K ? p.kch : p.K;
-            stage_rows<C>(cbl, p.cb + (size_t)(shared_cb ? 0 : 1) * p.K * C, rows);
-        }
-        land_bias(bin_own);
-        TL_STAMP();
-        __syncthreads();
-        TL_STAMP();
-        if (!(p.ablate & 1)) issue_dma(2);
-        TL_STAMP();
-        if (!(p.ablate & 2)) quantise(1, bin_own);
-        TL_STAMP();
-        slot_end();
-        TL_STAMP();
+        pass_out(T{}, F{});
+        pass_in();
+        restage(1);
+        slot(1, bin_own);
     }
     for (int l = 1; l + 1 < p.levels; ++l) {
         bin_own = bias_of(l + 1);
-        if (!(p.ablate & 4)) pass(T{}, T{}, F{});         // apply level l, project onto level l+1
-        if (!stage_once) {
-            const int rows = p.kch < p.K ? p.kch : p.K;
-            stage_rows<C>(cbl, p.cb + (size_t)(shared_cb ? 0 : l + 1) * p.K * C, rows);
+        if (!(p.ablate & 4)) {                            // apply level l, project onto level l+1
+            pass_out(F{}, F{});
+            pass_in();
         }
-        land_bias(bin_own);
-        TL_STAMP();
-        __syncthreads();
-        TL_STAMP();
-        if (!(p.ablate & 1)) issue_dma(l + 2);
-        TL_STAMP();
-        if (!(p.ablate & 2)) quantise(l + 1, bin_own);
-        TL_STAMP();
-        slot_end();
-        TL_STAMP();
+        restage(l + 1);
+        slot(l + 1, bin_own);
     }
-    if (p.levels > 1) pass(T{}, F{}, F{});                // apply the last level
-    else pass(T{}, F{}, T{});
+    if (p.levels > 1) pass_out(F{}, T{});                 // apply the last level
+    else pass_out(T{}, T{});
     TL_STAMP();
 #ifdef RQAE_TIMELINE
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory");
@@ -1119,9 +1174,8 @@ template <int P, int C>
 int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
 {
     constexpr int TG = 16;
-    constexpr int QI = (2 * C + 1 + 3) / 4;
     EncParams q = p;
-    const size_t fixed = sizeof(float) * ((size_t)NSLICE * P * QI * 256 + NSLICE * TG * C + ((TG * C + 3) & ~3));
+    const size_t fixed = sizeof(float) * ((size_t)NSLICE * rec_quads(P, C) * 256 + NSLICE * TG * C + ((TG * C + 3) & ~3));
     const size_t cb_budget = 160 * 1024 - fixed - 1024;
     int kch = (int)(cb_budget / (sizeof(float) * cb_lds_floats(C, 1)));
     kch = (kch / 64) * 64;
@@ -1415,14 +1469,14 @@ __global__ void __launch_bounds__(512, 2)
 rqae_decode_lds_kernel(const DecParams p)
 {
     constexpr int TPW = 8, NW = 8, TG = 16, NPAIR = 4, NG = 2, LCH = 32;
-    constexpr int QI = (2 * C + 1 + 3) / 4;      // quads per element step in the pass record
-    constexpr int QD = (C + 1 + 3) / 4;          // leading quads that hold w_out[0..C-1], b_out
-    static_assert(QD <= QI && QD * 1024 <= 4096, "decode reads a prefix of the record's quads");
-    constexpr int BUF = NSLICE * P * QD * 256;   // floats per weight buffer
+    constexpr int NQ = rec_quads(P, C);          // quads per lane per slice in a pass record
+    constexpr int QD = rec_out_quads(P, C);      // its leading quads: the packed {w_out[0..C-1], b_out} stream
+    constexpr int W = C + 1;
+    constexpr int BUF = NSLICE * QD * 256;       // floats per weight buffer
     constexpr int dp = 256 * P;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wbuf = smem;                          // [2][slice][i][QD][lane][4]
+    float *wbuf = smem;                          // [2][slice][QD][lane][4]
     float *cvl = wbuf + 2 * BUF;                 // [LCH][C][TG]  (token pairs contiguous)
 
     const int lane = threadIdx.x & 63;
@@ -1437,9 +1491,11 @@ rqae_decode_lds_kernel(const DecParams p)
     auto next_on = [&](int l) { while (l < p.nlev && !level_on(l)) ++l; return l; };   // uniform scalar loop
     // lin_out quads of level l (record l+1) -> buffer b; the 8 waves share the (slice, i) chunks
     auto issue_dma = [&](int l, int b) {
-        const float *rec = p.rec_p + (size_t)(l + 1) * NSLICE * P * QI * 256;
-        for (int ch = wave; ch < NSLICE * P; ch += NW)
-            dma_pieces<QD>(rec + (size_t)ch * QI * 256, wbuf_addr + (b * BUF + ch * QD * 256) * 4, lane * 16);
+        const float *rec = p.rec_p + (size_t)(l + 1) * NSLICE * NQ * 256;
+        for (int pc = wave; pc < NSLICE * QD; pc += NW) {
+            const int s = pc / QD, q = pc - s * QD;
+            dma_pieces<1>(rec + (size_t)(s * NQ + q) * 256, wbuf_addr + (b * BUF + pc * 256) * 4, lane * 16);
+        }
     };
 
     f2 acc[P][NPAIR];
@@ -1477,36 +1533,42 @@ rqae_decode_lds_kernel(const DecParams p)
         __syncthreads();                                      // weights of level l + codebook values visible
         if (ln < p.nlev) issue_dma(ln, buf ^ 1);              // next selected level loads behind this one
 
-        const f4 *wl = reinterpret_cast<const f4 *>(wbuf + buf * BUF) + (size_t)slice * P * QD * 64 + lane;
+        const f4 *wl = reinterpret_cast<const f4 *>(wbuf + buf * BUF) + (size_t)slice * QD * 64 + lane;
         const float *cvp = cvl + (l - staged_from) * C * TG + half * TPW;
+        // element step outermost: every weight quad is read from LDS once for the wave's 8 tokens
+        f2 cv2[NG][2][C];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            f2 cv2[2][C];
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
                     const f2 v = *reinterpret_cast<const f2 *>(cvp + k * TG + 4 * g + 2 * pr);
-                    cv2[pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
+                    cv2[g][pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
                 }
+        f4 wq[QD];
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                float w[QD * 4];
+        for (int q = 0; q < QD; ++q)
+            if (q <= last_quad_of_step(0, W)) wq[q] = wl[q * 64];
 #pragma unroll
-                for (int qd = 0; qd < QD; ++qd) {
-                    const f4 v = wl[(i * QD + qd) * 64];
-                    w[4 * qd] = v.x; w[4 * qd + 1] = v.y; w[4 * qd + 2] = v.z; w[4 * qd + 3] = v.w;
-                }
+        for (int i = 0; i < P; ++i) {
+#pragma unroll
+            for (int q = 0; q < QD; ++q)
+                if (i + 1 < P && q > last_quad_of_step(i, W) && q <= last_quad_of_step(i + 1, W)) wq[q] = wl[q * 64];
+            float w[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) w[k] = f4_get(wq[(i * W + k) / 4], (i * W + k) % 4);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     f2 y = splat2(0.0f);
 #pragma unroll
-                    for (int k = 0; k < C; ++k) y = fma2(cv2[pr][k], splat2(w[k]), y);
+                    for (int k = 0; k < C; ++k) y = fma2(cv2[g][pr][k], splat2(w[k]), y);
                     y = y + splat2(w[C]);
                     if (first) acc[i][2 * g + pr] = y;         // first selected level assigns (model.py:244-247)
                     else acc[i][2 * g + pr] = acc[i][2 * g + pr] + y;
                 }
-            }
         }
         first = false;
         l = ln;
@@ -1532,8 +1594,8 @@ rqae_decode_lds_kernel(const DecParams p)
 template <int P, int C>
 int launch_decode_lds(const DecParams &p, bool from_idx, hipStream_t stream)
 {
-    constexpr int QD = (C + 1 + 3) / 4;
-    const size_t lds = sizeof(float) * (2 * (size_t)NSLICE * P * QD * 256 + 32 * C * 16);
+    constexpr int QD = rec_out_quads(P, C);
+    const size_t lds = sizeof(float) * (2 * (size_t)NSLICE * QD * 256 + 32 * C * 16);
     const long long nblk = (p.n_tokens + 15) / 16;
     if (nblk > 0x7fffffffLL) return fail("decode: too many tokens for one launch");
     auto go = [&](auto kern) -> int {
@@ -1742,7 +1804,7 @@ int rqae_hip_pack(void *packed, int d, int c, int K, int L, const float *w_in, c
                        reinterpret_cast<float *>(b + lo.w_in), reinterpret_cast<float *>(b + lo.w_out),
                        reinterpret_cast<float *>(b + lo.b_out), w_in, w_out, b_out);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(pack_records_kernel, dim3(2048), dim3(256), 0, s, h, lo.qi,
+    hipLaunchKernelGGL(pack_records_kernel, dim3(2048), dim3(256), 0, s, h, lo.nq, rec_out_quads(lo.dp / 256, c),
                        reinterpret_cast<float *>(b + lo.rec_p), w_in, w_out, b_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b + lo.b_in, b_in, sizeof(float) * (size_t)L * c, hipMemcpyDeviceToDevice, s));

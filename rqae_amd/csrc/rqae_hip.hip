@@ -818,22 +818,28 @@ rqae_encode_lds_kernel(const EncParams p)
     const bool act = tq < TQ && jj < C;
 
     const unsigned wts_addr = lds_addr_of(wts);
-    // The record of pass pl goes to `wts` in 1-KiB pieces; the 8 waves share the pieces.  A wave's pieces are
-    // issued ONE AT A TIME from inside its quantise phase (dma_step): a burst of ~13 global_load_lds per wave
-    // blocks on the TA's address queue for ~1 800 cycles per level (measured, profiles/r01_timeline_*).
-    int dma_next = NPIECE;                   // next piece of this wave (>= NPIECE: nothing to issue)
+    // The record of pass pl goes to `wts` in 1-KiB pieces; every wave owns a contiguous run of them and issues
+    // it a few pieces at a time from inside its quantise phase (dma_trip, once per 256 codebook rows): a burst
+    // of ~13 global_load_lds per wave blocks on the TA's address queue for ~1 800 cycles per level (measured,
+    // profiles/r01_timeline_*).  Four consecutive pieces share one M0 set-up (immediate offsets).
+    int dma_next = 0, dma_end = 0;
     const float *dma_src = p.rec_p;
-    auto dma_begin = [&](int pl, int first_piece) {
+    auto dma_begin = [&](int pl) {
+        constexpr int PER = (NPIECE + NW - 1) / NW;
         dma_src = p.rec_p + (size_t)pl * WFLOATS;
-        dma_next = first_piece + wave;
+        dma_next = wave * PER;
+        dma_end = dma_next + PER < NPIECE ? dma_next + PER : NPIECE;
     };
-    auto dma_step = [&]() __attribute__((always_inline)) {
-        if (dma_next < NPIECE) {
+    auto dma_trip = [&]() __attribute__((always_inline)) {
+        if (dma_end - dma_next >= 4) {
+            dma_pieces<4>(dma_src + dma_next * 256, wts_addr + dma_next * 1024, lane * 16);
+            dma_next += 4;
+        } else if (dma_next < dma_end) {
             dma_pieces<1>(dma_src + dma_next * 256, wts_addr + dma_next * 1024, lane * 16);
-            dma_next += NW;
+            dma_next += 1;
         }
     };
-    auto dma_flush = [&]() { while (dma_next < NPIECE) dma_step(); };
+    auto dma_flush = [&]() { while (dma_next < dma_end) dma_trip(); };
 
     {   // record 0: only its lin_in part is read
         for (int s = 0; s < NSLICE; ++s)
@@ -1032,7 +1038,6 @@ rqae_encode_lds_kernel(const EncParams p)
                 __syncthreads();
             }
             auto scan_block = [&](int r0, bool in) __attribute__((always_inline)) {
-                dma_step();   // one piece of the next record per 64 codebook rows
                 const int row = r0 + lane;
                 float cbv[C];
                 load_row<C>(cbv, cbl, in ? row : 0, rows);
@@ -1054,6 +1059,7 @@ rqae_encode_lds_kernel(const EncParams p)
             // four 64-row blocks per trip, written out (hipcc will not unroll this loop on request)
             const int full4 = rows & ~255, full = rows & ~63;
             for (int r0 = 0; r0 < full4; r0 += 256) {
+                dma_trip();   // a few pieces of the next record per 256 codebook rows
                 scan_block(r0, true);
                 scan_block(r0 + 64, true);
                 scan_block(r0 + 128, true);
@@ -1113,7 +1119,7 @@ rqae_encode_lds_kernel(const EncParams p)
         TL_STAMP();
         __syncthreads();
         TL_STAMP();
-        if (!(p.ablate & 1)) dma_begin(l + 1, 0);
+        if (!(p.ablate & 1)) dma_begin(l + 1);
         if (!(p.ablate & 2)) quantise(l, bin_own);
         else dma_flush();
         TL_STAMP();

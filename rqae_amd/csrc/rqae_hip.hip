@@ -1029,6 +1029,7 @@ rqae_encode_lds_kernel(const EncParams p)
 #pragma unroll
             for (int k = 0; k < C; ++k) xs2[k] = (f2){lane_bcast(xn_own, k), lane_bcast(xn_own, JW + k)};
         }
+        TL_STAMP();   // unit vectors ready
         for (int ch = 0; ch < nchunk; ++ch) {
             const int row_base = ch * p.kch;
             const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
@@ -1060,15 +1061,40 @@ rqae_encode_lds_kernel(const EncParams p)
             const int full4 = rows & ~255, full = rows & ~63;
             for (int r0 = 0; r0 < full4; r0 += 256) {
                 dma_trip();   // a few pieces of the next record per 256 codebook rows
-                scan_block(r0, true);
-                scan_block(r0 + 64, true);
-                scan_block(r0 + 128, true);
-                scan_block(r0 + 192, true);
+                if constexpr (MFMA) {
+                    scan_block(r0, true);
+                    scan_block(r0 + 64, true);
+                    scan_block(r0 + 128, true);
+                    scan_block(r0 + 192, true);
+                } else {
+                    // Written as three phases with scheduling fences: left to itself hipcc (at the register limit)
+                    // runs the four blocks one after the other, each waiting out its own LDS read and its own
+                    // five-deep fma chain -- ~210 cycles per block, the largest single item of the quantise phase.
+                    float cb4[4][C];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) load_row<C>(cb4[b], cbl, r0 + 64 * b + lane, rows);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f2 s4[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) s4[b] = splat2(0.0f);
+#pragma unroll
+                    for (int k = 0; k < C; ++k)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) s4[b] = fma2(xs2[k], splat2(cb4[b][k]), s4[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int row = row_base + r0 + 64 * b + lane;
+                        if (s4[b].x > best[0]) { best[0] = s4[b].x; bidx[0] = row; }
+                        if (s4[b].y > best[1]) { best[1] = s4[b].y; bidx[1] = row; }
+                    }
+                }
             }
             for (int r0 = full4; r0 < full; r0 += 64) scan_block(r0, true);
             if (full < rows) scan_block(full, full + lane < rows);
         }
         dma_flush();   // small codebooks: fewer scan blocks than pieces
+        TL_STAMP();   // scan done
         // wave-wide first maximum per token: max by reduce-scatter, then the lowest row among its holders
         float mx[1];
         ReduceScatter<TQ, 0, 1, 1>::run(best, mx, lane);
@@ -1090,10 +1116,20 @@ rqae_encode_lds_kernel(const EncParams p)
                 win[t] = __builtin_amdgcn_readlane(bidx[t], __builtin_ctzll(tie));
             }
         }
+        TL_STAMP();   // wave-wide winners known
         if (act) {
             const int mine = tq == 1 ? win[1] : win[0];
-            const float rowv = nchunk == 1 ? row_elem<C>(cbl, mine, jj, p.kch < p.K ? p.kch : p.K)
-                                           : p.cb[((size_t)(shared_cb ? 0 : l) * p.K + mine) * C + jj];
+            // two separate loads: a pointer select here becomes one flat_load, whose wait is vmcnt(0) -- i.e.
+            // for the whole record in flight behind this phase
+            // (the LDS read in asm: hipcc otherwise still folds both sides into one flat_load)
+            float rowv;
+            if (nchunk == 1) {
+                const int rs = p.kch < p.K ? p.kch : p.K;
+                const float *src = (C <= 4 || jj < 4) ? cbl + mine * 4 + jj : cbl + (size_t)rs * 4 + mine * (C - 4) + (jj - 4);
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rowv) : "v"(lds_addr_of(src)) : "memory");
+            } else {
+                rowv = p.cb[((size_t)(shared_cb ? 0 : l) * p.K + mine) * C + jj];
+            }
             const float diff = rowv - q_own;                  // straight-through value (model.py:218-220)
             cvs[jj * TG + tl_q] = q_own + diff;
             const long long tok = tok0 + tl_q;

@@ -73,8 +73,12 @@ constexpr int rec_out_quads(int P, int C) { return quads_of(P * (C + 1)); }   //
 constexpr int rec_in_quads(int P, int C) { return quads_of(P * C); }          // {w_in[0..C-1]} per element
 constexpr int rec_quads(int P, int C) { return rec_out_quads(P, C) + rec_in_quads(P, C); }
 
+// floats of `rows` codebook rows in the LDS kernel's layout (stage_rows below)
+constexpr int cb_lds_floats(int C, int rows) { return rows * (C <= 4 ? 4 : 4 + (C - 4)); }
+
 struct Layout {
-    size_t w_in, w_out, b_out, b_in, cb, rec_p, total;
+    size_t w_in, w_out, b_out, b_in, cb, rec_p, cb_img, total;
+    int cb_img_pieces;  // 1-KiB pieces of the level-0 codebook in LDS layout
     int dp, nq;  // nq: float4s per lane per slice in a pass record
 };
 
@@ -98,6 +102,10 @@ Layout make_layout(int d, int c, int K, int L)
     //   quads [QOUT, NQ):   n = i*c + j       { w_in[pl][j][el] }
     lo.nq = rec_quads(lo.dp / 256, c);
     lo.rec_p = off; off += align256(sizeof(float) * (size_t)(L + 1) * NSLICE * lo.nq * 256);
+    // Level-0 codebook exactly as the LDS kernel keeps it ([K][4] head columns, then [K][c-4]), padded to whole
+    // 1-KiB pieces, so a workgroup stages it by LDS-DMA without touching a register.
+    lo.cb_img_pieces = (cb_lds_floats(c, K) + 255) / 256;
+    lo.cb_img = off; off += align256(sizeof(float) * (size_t)lo.cb_img_pieces * 256);
     lo.total = off;
     return lo;
 }
@@ -148,6 +156,23 @@ __global__ void pack_records_kernel(Header h, int nq, int qout, float *rec_p, co
             }
         }
         rec_p[u] = val;
+    }
+}
+
+// Level-0 codebook in the LDS layout of stage_rows (see make_layout).  One thread per float of the image.
+__global__ void pack_cb_image_kernel(int c, int K, int n_img, float *img, const float *codebook)
+{
+    const int tail = c > 4 ? c - 4 : 0;
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_img; u += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (u < K * 4) {
+            const int r = u >> 2, k = u & 3;
+            if (k < c) v = codebook[(size_t)r * c + k];
+        } else if (u < K * 4 + K * tail) {
+            const int r = (u - K * 4) / tail, k = 4 + (u - K * 4) % tail;
+            v = codebook[(size_t)r * c + k];
+        }
+        img[u] = v;
     }
 }
 
@@ -377,6 +402,8 @@ struct EncParams {
     int aligned16;  // x and q_out 16-byte aligned: full tiles may use vector loads/stores
     int ablate;  // RQAE_HIP_ABLATE bits: timing experiments only, results are wrong when != 0
     int tl_lds_floats;  // RQAE_TIMELINE builds: float offset of the stamp buffer in LDS
+    const float *cb_img;  // level-0 codebook in LDS layout (make_layout), cb_img_pieces KiB
+    int cb_img_pieces;
 };
 
 // P  : elements per lane per slice (dp = 256*P)      C : codebook_dim
@@ -656,7 +683,6 @@ __device__ __forceinline__ float lane_bcast_first(float v)
 }
 // Codebook rows in LDS for the LDS kernel: columns 0..3 of every row as one float4 (conflict-free
 // ds_read_b128, 16-byte lane stride), the remaining C-4 columns in a second array behind them.
-constexpr int cb_lds_floats(int C, int rows) { return rows * (C <= 4 ? 4 : 4 + (C - 4)); }
 template <int C>
 __device__ __forceinline__ void stage_rows(float *dst, const float *src, int rows)
 {
@@ -845,8 +871,13 @@ rqae_encode_lds_kernel(const EncParams p)
         for (int s = 0; s < NSLICE; ++s)
             for (int q = QOUT + wave; q < NQ; q += NW)
                 dma_pieces<1>(p.rec_p + (s * NQ + q) * 256, wts_addr + (s * NQ + q) * 1024, lane * 16);
-        const int rows = p.kch < p.K ? p.kch : p.K;
-        stage_rows<C>(cbl, p.cb, rows);
+        if (nchunk == 1) {   // level-0 codebook: its LDS image by DMA -- no registers, no wait in front of the x loads
+            const unsigned cbl_addr = lds_addr_of(cbl);
+            for (int pc = wave; pc < p.cb_img_pieces; pc += NW)
+                dma_pieces<1>(p.cb_img + pc * 256, cbl_addr + pc * 1024, lane * 16);
+        } else {
+            stage_rows<C>(cbl, p.cb, p.kch);
+        }
     }
 
     f2 r2[P][NPAIR];
@@ -1230,10 +1261,12 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
     }
     const int rows = kch < p.K ? kch : p.K;
 #ifdef RQAE_TIMELINE
-    q.tl_lds_floats = (int)((fixed / sizeof(float) + cb_lds_floats(C, rows) + 3) & ~(size_t)3);
+    const size_t cbf_tl = kch >= p.K ? (size_t)p.cb_img_pieces * 256 : (size_t)cb_lds_floats(C, rows);
+    q.tl_lds_floats = (int)((fixed / sizeof(float) + cbf_tl + 3) & ~(size_t)3);
     const size_t lds = sizeof(float) * (size_t)q.tl_lds_floats + 8 * 64 * sizeof(long long);
 #else
-    const size_t lds = fixed + sizeof(float) * (size_t)cb_lds_floats(C, rows);
+    const size_t cbf = kch >= p.K ? (size_t)p.cb_img_pieces * 256 : (size_t)cb_lds_floats(C, rows);   // whole pieces when DMA-staged
+    const size_t lds = fixed + sizeof(float) * cbf;
 #endif
     const long long nblk = (p.n_tokens + TG - 1) / TG;
     if (nblk > 0x7fffffffLL) return fail("encode: too many tokens for one launch");
@@ -1757,8 +1790,8 @@ gemma_denorm_patch_kernel(const float *q, const float *w, const float *rs, long 
 
 struct PackedView {
     const Header *hdr;
-    const float *w_in, *w_out, *b_out, *b_in, *cb, *rec_p;
-    int dp;
+    const float *w_in, *w_out, *b_out, *b_in, *cb, *rec_p, *cb_img;
+    int dp, cb_img_pieces;
 };
 
 PackedView view_of(const void *packed, int d, int c, int K, int L)
@@ -1772,6 +1805,8 @@ PackedView view_of(const void *packed, int d, int c, int K, int L)
     v.b_out = reinterpret_cast<const float *>(b + lo.b_out);
     v.b_in = reinterpret_cast<const float *>(b + lo.b_in);
     v.cb = reinterpret_cast<const float *>(b + lo.cb);
+    v.cb_img = reinterpret_cast<const float *>(b + lo.cb_img);
+    v.cb_img_pieces = lo.cb_img_pieces;
     v.rec_p = reinterpret_cast<const float *>(b + lo.rec_p);
     v.dp = lo.dp;
     return v;
@@ -1851,6 +1886,9 @@ int rqae_hip_pack(void *packed, int d, int c, int K, int L, const float *w_in, c
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b + lo.b_in, b_in, sizeof(float) * (size_t)L * c, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(b + lo.cb, codebook, sizeof(float) * (size_t)L * K * c, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(pack_cb_image_kernel, dim3(256), dim3(256), 0, s, c, K, lo.cb_img_pieces * 256,
+                       reinterpret_cast<float *>(b + lo.cb_img), codebook);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1867,7 +1905,7 @@ int rqae_hip_encode(const void *packed, int d, int c, int K, int L, const void *
     EncParams p;
     memset(&p, 0, sizeof(p));
     p.w_in = v.w_in; p.w_out = v.w_out; p.b_out = v.b_out; p.b_in = v.b_in; p.cb = v.cb; p.hdr = v.hdr;
-    p.rec_p = v.rec_p;
+    p.rec_p = v.rec_p; p.cb_img = v.cb_img; p.cb_img_pieces = v.cb_img_pieces;
     p.x = x; p.q_out = q_out; p.idx = reinterpret_cast<long long *>(indices);
     p.n_tokens = n_tokens; p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.levels = levels; p.x_dtype = x_dtype;
     p.aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q_out)) & 15) == 0;

@@ -802,6 +802,29 @@ __device__ __forceinline__ void pk_fma_bcast(f2 &acc, f2 a, const f4 &quad, int 
     if ((c & 1) == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(pair));
     else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(a), "v"(pair));
 }
+// The same with a wave-uniform multiplicand in an SGPR pair (lin_out: y += cv * w), as `asm volatile`: the
+// order in which these are written is the order in which they issue.  lin_out's four token pairs are written
+// k-outermost, so that consecutive instructions are independent -- left to itself hipcc runs the four
+// eight-deep dependent chains one after the other (one issue per ~10 cycles per wave instead of ~6).
+// first: the chain starts from +0 (y = cv * w + 0).
+__device__ __forceinline__ void pk_fma_bcast_s(f2 &y, f2 cv_uniform, const f4 &quad, int c, bool first)
+{
+    const f2 pair = c < 2 ? __builtin_shufflevector(quad, quad, 0, 1) : __builtin_shufflevector(quad, quad, 2, 3);
+    if (first) {
+        if ((c & 1) == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(y) : "s"(cv_uniform), "v"(pair));
+        else asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(y) : "s"(cv_uniform), "v"(pair));
+    } else {
+        if ((c & 1) == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(y) : "s"(cv_uniform), "v"(pair));
+        else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(y) : "s"(cv_uniform), "v"(pair));
+    }
+}
+// y += broadcast(component c of quad)
+__device__ __forceinline__ void pk_add_bcast(f2 &y, const f4 &quad, int c)
+{
+    const f2 pair = c < 2 ? __builtin_shufflevector(quad, quad, 0, 1) : __builtin_shufflevector(quad, quad, 2, 3);
+    if ((c & 1) == 0) asm volatile("v_pk_add_f32 %0, %1, %0 op_sel_hi:[0,1]" : "+v"(y) : "v"(pair));
+    else asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[1,0]" : "+v"(y) : "v"(pair));
+}
 
 template <int P, int C, bool RECON, bool MFMA>
 __global__ void __launch_bounds__(512, 2)
@@ -930,6 +953,7 @@ rqae_encode_lds_kernel(const EncParams p)
                     }
             }
         }
+        if constexpr (!MFMA) asm volatile("s_nop 3" ::: "memory");   // v_readfirstlane -> SGPR read by the asm below
         f4 wq[QOUT];          // SSA values: each quad lives from its read (one step ahead) to its last use
 #pragma unroll
         for (int q = 0; q < QOUT; ++q)
@@ -939,32 +963,39 @@ rqae_encode_lds_kernel(const EncParams p)
 #pragma unroll
             for (int q = 0; q < QOUT; ++q)
                 if (i + 1 < P && q > last_quad_of_step(i, W) && q <= last_quad_of_step(i + 1, W)) wq[q] = wl[q * 64];
-            float w[W];
+            f2 yy[NG][2];
+            if constexpr (MFMA) {
+                float w[W];
 #pragma unroll
-            for (int k = 0; k < W; ++k) w[k] = f4_get(wq[(i * W + k) / 4], (i * W + k) % 4);
+                for (int k = 0; k < W; ++k) w[k] = f4_get(wq[(i * W + k) / 4], (i * W + k) % 4);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                f2 ym[2];
-                if constexpr (MFMA) {
+                for (int g = 0; g < NG; ++g) {
                     f4 y4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                     for (int k = 0; k < C; ++k) y4 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cv[g][k], w[k], y4, 4, 0, 0);
                     y4 = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, w[C], y4, 4, 0, 0);   // + bias, one rounding
-                    ym[0] = (f2){y4.x, y4.y};
-                    ym[1] = (f2){y4.z, y4.w};
+                    yy[g][0] = (f2){y4.x, y4.y};
+                    yy[g][1] = (f2){y4.z, y4.w};
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; ++k)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr)
+                            pk_fma_bcast_s(yy[g][pr], cv2[g][pr][k], wq[(i * W + k) / 4], (i * W + k) % 4, k == 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) pk_add_bcast(yy[g][pr], wq[(i * W + C) / 4], (i * W + C) % 4);
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     f2 &rr = r2[i][2 * g + pr];
-                    f2 y;
-                    if constexpr (MFMA) {
-                        y = ym[pr];
-                    } else {
-                        y = splat2(0.0f);
-#pragma unroll
-                        for (int k = 0; k < C; ++k) y = fma2(cv2[g][pr][k], splat2(w[k]), y);
-                        y = y + splat2(w[C]);
-                    }
+                    const f2 y = yy[g][pr];
                     rr = rr - y;
                     if constexpr (RECON) {
                         if constexpr (FIRST) out2[i][2 * g + pr] = splat2(0.0f) + y;

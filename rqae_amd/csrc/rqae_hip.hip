@@ -1652,6 +1652,7 @@ rqae_decode_lds_kernel(const DecParams p)
                     const f2 v = *reinterpret_cast<const f2 *>(cvp + k * TG + 4 * g + 2 * pr);
                     cv2[g][pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
                 }
+        asm volatile("s_nop 3" ::: "memory");   // v_readfirstlane -> SGPR read by the asm below
         f4 wq[QD];
 #pragma unroll
         for (int q = 0; q < QD; ++q)
@@ -1661,19 +1662,21 @@ rqae_decode_lds_kernel(const DecParams p)
 #pragma unroll
             for (int q = 0; q < QD; ++q)
                 if (i + 1 < P && q > last_quad_of_step(i, W) && q <= last_quad_of_step(i + 1, W)) wq[q] = wl[q * 64];
-            float w[W];
+            f2 yy[NG][2];   // the four chains interleaved, as in the encode kernel's sweep 1
 #pragma unroll
-            for (int k = 0; k < W; ++k) w[k] = f4_get(wq[(i * W + k) / 4], (i * W + k) % 4);
+            for (int k = 0; k < C; ++k)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr)
+                        pk_fma_bcast_s(yy[g][pr], cv2[g][pr][k], wq[(i * W + k) / 4], (i * W + k) % 4, k == 0);
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    f2 y = splat2(0.0f);
-#pragma unroll
-                    for (int k = 0; k < C; ++k) y = fma2(cv2[g][pr][k], splat2(w[k]), y);
-                    y = y + splat2(w[C]);
-                    if (first) acc[i][2 * g + pr] = y;         // first selected level assigns (model.py:244-247)
-                    else acc[i][2 * g + pr] = acc[i][2 * g + pr] + y;
+                    pk_add_bcast(yy[g][pr], wq[(i * W + C) / 4], (i * W + C) % 4);
+                    if (first) acc[i][2 * g + pr] = yy[g][pr];     // first selected level assigns (model.py:244-247)
+                    else acc[i][2 * g + pr] = acc[i][2 * g + pr] + yy[g][pr];
                 }
         }
         first = false;

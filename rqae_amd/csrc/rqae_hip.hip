@@ -1382,9 +1382,9 @@ const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream
     // Bit-identical output; measured 10-17 % slower than the packed-VALU arm on MI355X.
     if (v == V_AUTO || v == V_M) {
         const bool m = v == V_M;
-        if (P == 9 && c == 5) RUNF(m ? "encode_lds<P=9,C=5> MFMA 4x4x1 arm" : "encode_lds<P=9,C=5> 8 waves x 8 tokens, LDS-DMA weights, fused pass in packed fp32", 9, 5);
-        if (P == 9 && c == 4) RUNF(m ? "encode_lds<P=9,C=4> MFMA 4x4x1 arm" : "encode_lds<P=9,C=4> 8 waves x 8 tokens, LDS-DMA weights, fused pass in packed fp32", 9, 4);
-        if (P == 1 && c == 4) RUNF(m ? "encode_lds<P=1,C=4> MFMA 4x4x1 arm" : "encode_lds<P=1,C=4> 8 waves x 8 tokens, LDS-DMA weights, fused pass in packed fp32", 1, 4);
+        if (P == 9 && c == 5) RUNF(m ? "encode_lds<P=9,C=5> MFMA 4x4x1 arm" : "encode_lds<P=9,C=5> 8 waves x 8 tokens, LDS-DMA weights, two-sweep pass in packed fp32", 9, 5);
+        if (P == 9 && c == 4) RUNF(m ? "encode_lds<P=9,C=4> MFMA 4x4x1 arm" : "encode_lds<P=9,C=4> 8 waves x 8 tokens, LDS-DMA weights, two-sweep pass in packed fp32", 9, 4);
+        if (P == 1 && c == 4) RUNF(m ? "encode_lds<P=1,C=4> MFMA 4x4x1 arm" : "encode_lds<P=1,C=4> 8 waves x 8 tokens, LDS-DMA weights, two-sweep pass in packed fp32", 1, 4);
     }
 #undef RUNF
     if (v != V_GEN) {

@@ -1785,6 +1785,54 @@ gemma_norm_kernel(const HT *hs, const float *w, float eps, long long n_tokens, i
     }
 }
 
+// Vector form for d % 4 == 0, d <= 1024*NJ, 16-byte aligned rows: hs is read ONCE (4 elements = one 8-byte
+// or 16-byte load per lane and step, kept in registers across the reduction) and normed written as float4.
+// Same arithmetic and order as gemma_norm_kernel.
+template <typename HT, int NJ>
+__global__ void __launch_bounds__(256)
+gemma_norm_vec_kernel(const HT *hs, const float *w, float eps, long long n_tokens, int d, float *normed, float *rs_out)
+{
+    typedef typename VecOf<HT, 4>::type H4;
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tokens) return;
+    const HT *row = hs + (size_t)tok * d;
+    float x[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e0 = 4 * (lane + 64 * j);
+        if (e0 < d) {
+            const H4 v = *reinterpret_cast<const H4 *>(row + e0);
+            x[j][0] = widen<HT>(v.x); x[j][1] = widen<HT>(v.y); x[j][2] = widen<HT>(v.z); x[j][3] = widen<HT>(v.w);
+        } else {
+            x[j][0] = x[j][1] = x[j][2] = x[j][3] = 0.0f;
+        }
+    }
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (4 * (lane + 64 * j) < d) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ss = fmaf(x[j][u], x[j][u], ss);
+        }
+    const float total = wave_tree_sum(ss, lane);
+    const float ms = total / (float)d;
+    const float rs = 1.0f / __builtin_sqrtf(ms + eps);
+    if (lane == 0) rs_out[tok] = rs;
+    float *orow = normed + (size_t)tok * d;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e0 = 4 * (lane + 64 * j);
+        if (e0 < d) {
+            const f4 wv = *reinterpret_cast<const f4 *>(w + e0);
+            f4 o;
+            o.x = (x[j][0] * rs) * (1.0f + wv.x); o.y = (x[j][1] * rs) * (1.0f + wv.y);
+            o.z = (x[j][2] * rs) * (1.0f + wv.z); o.w = (x[j][3] * rs) * (1.0f + wv.w);
+            __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(orow + e0));
+        }
+    }
+}
+
 template <typename HT>
 __device__ __forceinline__ HT narrow(float v);
 template <>
@@ -1819,6 +1867,43 @@ gemma_denorm_patch_kernel(const float *q, const float *w, const float *rs, long 
         }
         if (nrow) nrow[e] = v;
         if (!bos) hrow[e] = narrow<HT>(v);                      // output[0].data.copy_(q_out)  (model.py:289)
+    }
+}
+
+// Vector form of the patch kernel (d % 4 == 0, 16-byte aligned rows): float4 in, 4 elements of the LLM's
+// dtype out per lane and step.  Same arithmetic as gemma_denorm_patch_kernel.
+template <typename HT>
+__global__ void __launch_bounds__(256)
+gemma_denorm_patch_vec_kernel(const float *q, const float *w, const float *rs, long long n_tokens, int d, int seq_len,
+                              int skip_bos, HT *hs_inout, float *new_out)
+{
+    typedef typename VecOf<HT, 4>::type H4;
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tokens) return;
+    const bool bos = skip_bos && (tok % seq_len) == 0;      // wave-uniform
+    const float r = rs[tok];
+    const float *qrow = q + (size_t)tok * d;
+    HT *hrow = hs_inout + (size_t)tok * d;
+    float *nrow = new_out ? new_out + (size_t)tok * d : nullptr;
+    if (bos) {                                               // q_out[:, 0] = hs[:, 0]  (model.py:285-286): hs stays
+        if (nrow)
+            for (int e0 = 4 * lane; e0 < d; e0 += 256) {
+                const H4 h = *reinterpret_cast<const H4 *>(hrow + e0);
+                *reinterpret_cast<f4 *>(nrow + e0) = (f4){widen<HT>(h.x), widen<HT>(h.y), widen<HT>(h.z), widen<HT>(h.w)};
+            }
+        return;
+    }
+    for (int e0 = 4 * lane; e0 < d; e0 += 256) {
+        const f4 qv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(qrow + e0));
+        const f4 wv = *reinterpret_cast<const f4 *>(w + e0);
+        f4 v;
+        v.x = (qv.x / (1.0f + wv.x)) / r; v.y = (qv.y / (1.0f + wv.y)) / r;   // rqae/llm.py:69-72
+        v.z = (qv.z / (1.0f + wv.z)) / r; v.w = (qv.w / (1.0f + wv.w)) / r;
+        if (nrow) *reinterpret_cast<f4 *>(nrow + e0) = v;
+        H4 o;
+        o.x = narrow<HT>(v.x); o.y = narrow<HT>(v.y); o.z = narrow<HT>(v.z); o.w = narrow<HT>(v.w);
+        *reinterpret_cast<H4 *>(hrow + e0) = o;             // output[0].data.copy_(q_out)  (model.py:289)
     }
 }
 
@@ -2012,6 +2097,22 @@ int rqae_hip_gemma_norm(const void *hs, int hs_dtype, const float *norm_weight, 
     const long long nblk = (n_tokens + 3) / 4;
     if (nblk > 0x7fffffffLL) return fail("gemma_norm: too many tokens for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t hsz = hs_dtype == RQAE_X_F32 ? 4 : 2;
+    const bool vec = d % 4 == 0 && d <= 4096 && (reinterpret_cast<uintptr_t>(hs) % (4 * hsz)) == 0 &&
+                     ((size_t)d * hsz) % (4 * hsz) == 0 && (reinterpret_cast<uintptr_t>(normed) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(norm_weight) & 15) == 0;
+    if (vec) {
+#define NORM_VEC(HT, NJ) hipLaunchKernelGGL((gemma_norm_vec_kernel<HT, NJ>), dim3((unsigned)nblk), dim3(256), 0, s, \
+                                            (const HT *)hs, norm_weight, eps, (long long)n_tokens, d, normed, inv_rms)
+#define NORM_VEC_D(HT) do { if (d <= 1024) NORM_VEC(HT, 4); else if (d <= 2304) NORM_VEC(HT, 9); else NORM_VEC(HT, 16); } while (0)
+        if (hs_dtype == RQAE_X_F16) NORM_VEC_D(_Float16);
+        else if (hs_dtype == RQAE_X_BF16) NORM_VEC_D(uint16_t);
+        else NORM_VEC_D(float);
+#undef NORM_VEC_D
+#undef NORM_VEC
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (hs_dtype == RQAE_X_F16)
         hipLaunchKernelGGL(gemma_norm_kernel<_Float16>, dim3((unsigned)nblk), dim3(256), 0, s, (const _Float16 *)hs, norm_weight, eps, (long long)n_tokens, d, normed, inv_rms);
     else if (hs_dtype == RQAE_X_BF16)
@@ -2033,6 +2134,20 @@ int rqae_hip_gemma_denorm_patch(const float *q_out, const float *norm_weight, co
     const long long nblk = (n_tokens + 3) / 4;
     if (nblk > 0x7fffffffLL) return fail("gemma_denorm_patch: too many tokens for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t hsz = hs_dtype == RQAE_X_F32 ? 4 : 2;
+    const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(hs_inout) % (4 * hsz)) == 0 &&
+                     (reinterpret_cast<uintptr_t>(q_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(norm_weight) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(new_out) & 15) == 0;
+    if (vec) {
+#define PATCH_VEC(HT) hipLaunchKernelGGL(gemma_denorm_patch_vec_kernel<HT>, dim3((unsigned)nblk), dim3(256), 0, s, q_out, \
+                                         norm_weight, inv_rms, (long long)n_tokens, d, seq_len, skip_bos, (HT *)hs_inout, new_out)
+        if (hs_dtype == RQAE_X_F16) PATCH_VEC(_Float16);
+        else if (hs_dtype == RQAE_X_BF16) PATCH_VEC(uint16_t);
+        else PATCH_VEC(float);
+#undef PATCH_VEC
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (hs_dtype == RQAE_X_F16)
         hipLaunchKernelGGL(gemma_denorm_patch_kernel<_Float16>, dim3((unsigned)nblk), dim3(256), 0, s, q_out, norm_weight, inv_rms, (long long)n_tokens, d, seq_len, skip_bos, (_Float16 *)hs_inout, new_out);
     else if (hs_dtype == RQAE_X_BF16)

@@ -10,7 +10,7 @@ import torch
 
 import oracle
 from conftest import FORWARD_CASES, case_inputs, load_golden, rel_err
-from rqae_amd import RQAE, synth
+from rqae_amd import RQAE, _native, synth
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
@@ -420,3 +420,30 @@ def test_fused_gemma_hook(dtype):
     with torch.inference_mode():
         m.hook(llm=llm, replace=False)(None, None, (hs3,))
     assert torch.equal(hs3, hs0)
+
+
+@pytest.mark.parametrize("d,dtype", [(2304, torch.float16), (2304, torch.float32), (1000, torch.bfloat16),
+                                     (250, torch.float16), (4100, torch.float32)])
+def test_gemma_norm_and_patch_kernels(d, dtype):
+    """Both code paths of the hook kernels (vector: d % 4 == 0 and d <= 4096; scalar otherwise), all dtypes,
+    bit for bit against the oracle's restatement."""
+    B, S = 2, 9
+    rng = np.random.Generator(np.random.PCG64(d))
+    hs_np = (rng.standard_normal((B, S, d)) * 2.5).astype(np.float32)
+    nw = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    hs = torch.from_numpy(hs_np).to(dtype).to(DEV)
+    hs_np = hs.float().cpu().numpy()                      # what the kernel sees after the dtype rounding
+    w = torch.from_numpy(nw).to(DEV)
+    normed, rs = _native.gemma_norm(hs, w, 1e-6)
+    normed_o, rs_o = oracle.gemma_norm_canonical(hs_np, nw)
+    assert np.array_equal(rs.cpu().numpy(), rs_o)
+    assert np.array_equal(normed.cpu().numpy(), normed_o)
+    q = torch.from_numpy((rng.standard_normal((B, S, d)) * 1.5).astype(np.float32)).to(DEV)
+    for skip_bos in (True, False):
+        h2 = hs.clone()
+        new = _native.gemma_denorm_patch(q, w, rs, h2, skip_bos, True)
+        new_o = oracle.gemma_denorm_canonical(q.cpu().numpy(), rs_o, nw)
+        if skip_bos:
+            new_o[:, 0] = hs_np[:, 0]
+        assert np.array_equal(new.cpu().numpy(), new_o)
+        assert torch.equal(h2, torch.from_numpy(new_o).to(dtype).to(DEV))

@@ -112,6 +112,25 @@ int rqae_hip_gemma_denorm_patch(const float *q_out, const float *norm_weight, co
                                 int64_t n_tokens, int d, int seq_len, int skip_bos, void *hs_inout,
                                 int hs_dtype, float *new_out, void *stream);
 
+/*
+ * RQAEFeature.intensity (rqae/feature.py:102-129): per token the running, weight-normalised similarity of its
+ * codes to a feature's centre codes, at the requested levels (the consumer of the codes this library writes).
+ *   rqae_hip_intensity_prepare, once per (feature, M = max(layers) + 1):
+ *       table[m][k] = codebook_sims[center[m]][k]   (fp16 [M][K]; codebook_sims is RQAE.codebook_sims, fp16 [K][K])
+ *       wcum[m]     = layer_weights[:M].cumsum()[m] in torch-CPU's order (fp32 accumulator, fp16 prefixes)
+ *   rqae_hip_intensity:
+ *       out[n][j] = fp16( fp16( sum_{m <= layers[j]} fp16(table[m][code[n][m]] * w[m]) ) / wcum[layers[j]] )
+ *       indices [n_tokens][nq] idx_dtype (RQAE_IDX_*), only columns < M are read and every code must be < K;
+ *       layers_dev [n_layers] int32 DEVICE array, each < M, any order, duplicates allowed;
+ *       table must be 16-byte aligned and allocated in whole 16-byte pieces; out [n_tokens][n_layers] fp16.
+ * Bit-equal to the reference (the level sum is a sequential fp32 chain per token; nothing is re-associated).
+ */
+int rqae_hip_intensity_prepare(const void *codebook_sims, const int *center, const void *layer_weights, int M, int K,
+                               void *table, void *wcum, void *stream);
+int rqae_hip_intensity(const void *table, const void *layer_weights, const void *wcum, int M, int K,
+                       const void *indices, int idx_dtype, int64_t n_tokens, int nq, const int *layers_dev,
+                       int n_layers, void *out, void *stream);
+
 /* Human-readable name of the encode kernel variant chosen for a shape. */
 int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);
 

@@ -14,4 +14,5 @@ from .oracle import (  # noqa: F401
     hook_reference,
     gemma_norm_canonical,
     gemma_denorm_canonical,
+    intensity,
 )

@@ -196,3 +196,29 @@ def gemma_denorm_canonical(q, rs, weight):
     w1 = (np.float32(1.0) + np.asarray(weight, np.float32)).astype(np.float32)
     t = (np.asarray(q, np.float32) / w1).astype(np.float32)
     return (t / np.asarray(rs, np.float32)[..., None]).astype(np.float32)
+
+
+def intensity(codebook_sims, center, layer_weights, token_indices, layers):
+    """RQAEFeature.intensity (rqae/feature.py:102-129) restated, torch-CPU fp16 semantics written out:
+    gather sims[..., m] = codebook_sims[center[m], idx[..., m]] (fp16); `sims *= w` = fp16(fp32(s) * fp32(w));
+    `cumsum` = sequential fp32 accumulator, every prefix rounded to fp16 (ATen cumsum_cpu_kernel: acc_type of
+    Half on CPU is float); `/= w.cumsum()` = fp16(fp32(prefix) / fp32(fp16 prefix of w)); then `[..., layers]`."""
+    layers = [int(l) for l in layers]
+    M = max(layers) + 1
+    T = np.asarray(codebook_sims, np.float16)
+    c = np.asarray(center)[:M].astype(np.int64)
+    idx = np.asarray(token_indices)[..., :M].astype(np.int64)
+    w = np.asarray(layer_weights, np.float16)[:M]
+    sims = T[c, idx]
+    sims = (sims.astype(np.float32) * w.astype(np.float32)).astype(np.float16)
+    acc = np.zeros(sims.shape[:-1], np.float32)
+    pref = np.empty_like(sims)
+    wacc = np.float32(0.0)
+    wc = np.empty(M, np.float16)
+    for m in range(M):
+        acc = (acc + sims[..., m].astype(np.float32)).astype(np.float32)
+        pref[..., m] = acc.astype(np.float16)
+        wacc = np.float32(wacc + np.float32(w[m]))
+        wc[m] = np.float16(wacc)
+    out = (pref.astype(np.float32) / wc.astype(np.float32)).astype(np.float16)
+    return out[..., layers]

@@ -8,5 +8,6 @@ There is no CPU fallback: calling the hot path without the HIP library or on a
 CPU tensor raises.
 """
 from .model import RQAE  # noqa: F401
+from .feature import Feature, RQAEFeature  # noqa: F401
 
-__all__ = ["RQAE"]
+__all__ = ["RQAE", "RQAEFeature", "Feature"]

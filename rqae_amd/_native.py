@@ -30,6 +30,8 @@ SYMBOLS = (
     "rqae_hip_decode_values",
     "rqae_hip_gemma_norm",
     "rqae_hip_gemma_denorm_patch",
+    "rqae_hip_intensity_prepare",
+    "rqae_hip_intensity",
     "rqae_hip_kernel_info",
 )
 
@@ -70,6 +72,10 @@ def lib():
     L.rqae_hip_gemma_norm.restype = i
     L.rqae_hip_gemma_denorm_patch.argtypes = [vp, vp, vp, i64, i, i, i, vp, i, vp, vp]
     L.rqae_hip_gemma_denorm_patch.restype = i
+    L.rqae_hip_intensity_prepare.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
+    L.rqae_hip_intensity_prepare.restype = i
+    L.rqae_hip_intensity.argtypes = [vp, vp, vp, i, i, vp, i, i64, i, vp, i, vp, vp]
+    L.rqae_hip_intensity.restype = i
     L.rqae_hip_kernel_info.argtypes = [i, i, i, i, ctypes.c_char_p, sz]
     L.rqae_hip_kernel_info.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
@@ -240,6 +246,45 @@ def gemma_denorm_patch(q_out: torch.Tensor, norm_weight: torch.Tensor, inv_rms: 
                                                    new.data_ptr() if want_new else None, _stream(q_out.device))
         _check(rc, "rqae_hip_gemma_denorm_patch")
     return new
+
+
+def intensity_prepare(codebook_sims: torch.Tensor, center: torch.Tensor, layer_weights: torch.Tensor, M: int):
+    """(table [M,K] f16 = codebook_sims[center[m]], wcum [M] f16 = layer_weights[:M].cumsum() in torch-CPU order);
+    rqae/feature.py:119-126.  Inputs on the device: codebook_sims [K,K] f16, center int32, layer_weights f16."""
+    _require_cuda(codebook_sims, "codebook_sims")
+    K = codebook_sims.shape[0]
+    if codebook_sims.dtype != torch.float16 or codebook_sims.shape != (K, K) or not codebook_sims.is_contiguous():
+        raise RuntimeError("intensity_prepare: codebook_sims must be a contiguous [K, K] float16 tensor")
+    dev = codebook_sims.device
+    c = center[:M].to(device=dev, dtype=torch.int32).contiguous()
+    w = layer_weights[:M].to(device=dev, dtype=torch.float16).contiguous()
+    if c.numel() != M or w.numel() != M:
+        raise RuntimeError("intensity_prepare: center / layer_weights shorter than max(layers) + 1")
+    n16 = (M * K * 2 + 15) // 16
+    table = torch.empty(n16 * 8, dtype=torch.float16, device=dev)   # whole 16-byte pieces
+    wcum = torch.empty(M, dtype=torch.float16, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().rqae_hip_intensity_prepare(codebook_sims.data_ptr(), c.data_ptr(), w.data_ptr(), M, K,
+                                              table.data_ptr(), wcum.data_ptr(), _stream(dev))
+    _check(rc, "rqae_hip_intensity_prepare")
+    return table, w, wcum
+
+
+def intensity(table, w, wcum, M: int, K: int, idx2d: torch.Tensor, layers_dev: torch.Tensor) -> torch.Tensor:
+    """idx2d [n, nq] int64/int32/uint16 on the device -> [n, n_layers] f16; rqae/feature.py:119-128."""
+    _require_cuda(idx2d, "token_indices")
+    if idx2d.dtype not in _IDX_DTYPES or not idx2d.is_contiguous() or idx2d.dim() != 2:
+        raise RuntimeError("intensity: token indices must be a contiguous [n, nq] int64/int32/uint16 tensor")
+    n, nq = idx2d.shape
+    nl = layers_dev.numel()
+    out = torch.empty((n, nl), dtype=torch.float16, device=idx2d.device)
+    if n:
+        with torch.cuda.device(idx2d.device):
+            rc = lib().rqae_hip_intensity(table.data_ptr(), w.data_ptr(), wcum.data_ptr(), M, K, idx2d.data_ptr(),
+                                          _IDX_DTYPES[idx2d.dtype], n, nq, layers_dev.data_ptr(), nl, out.data_ptr(),
+                                          _stream(idx2d.device))
+        _check(rc, "rqae_hip_intensity")
+    return out
 
 
 def kernel_info(d: int, c: int, K: int, L: int) -> str:

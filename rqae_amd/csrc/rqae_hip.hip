@@ -1907,6 +1907,136 @@ gemma_denorm_patch_vec_kernel(const float *q, const float *w, const float *rs, l
     }
 }
 
+// =============================================================== feature intensity
+// RQAEFeature.intensity (rqae/feature.py:102-129): for every token n and every requested level l
+//     sims[n][m] = codebook_sims[center[m], code[n][m]] * w[m]            (fp16 product)
+//     out[n][l]  = fp16( fp16(sum_{m<=l} sims[n][m]) / wcum[l] )           (fp32 running sum, sequential)
+// with torch-CPU's fp16 semantics written out (oracle/oracle.py:intensity restates them; bit-equal to the
+// reference's output).  One lane = one token, levels strictly in order (the sum is a sequential fp32 chain, so
+// there is no parallel scan).  HBM-bound on the code matrix: a wave reads its 64 tokens x TL levels tile with
+// fully coalesced 16-byte loads (one tile ahead, in registers), transposes it through LDS and walks its own
+// row; the per-level table rows (codebook_sims[center[m], :], K fp16 each) sit in LDS a chunk of levels at a time.
+struct IntensityParams {
+    const _Float16 *table;    // [M][K]  = codebook_sims[center[m], :]
+    const _Float16 *w, *wcum; // [M]
+    const void *idx;
+    const int *layers;        // [n_layers] device
+    _Float16 *out;            // [n_tokens][n_layers]
+    long long n_tokens;
+    int nq, M, K, LC, n_layers, vec_ok;
+};
+
+__global__ void intensity_prepare_kernel(const _Float16 *sims, const int *center, const _Float16 *w, int M, int K,
+                                         _Float16 *table, _Float16 *wcum)
+{
+    const size_t n = (size_t)M * K;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(u / K), k = (int)(u % K);
+        table[u] = sims[(size_t)center[m] * K + k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // layer_weights[:M].cumsum(): fp32 accumulator, fp16 prefixes
+        float acc = 0.0f;
+        for (int m = 0; m < M; ++m) {
+            acc += (float)w[m];
+            wcum[m] = (_Float16)acc;
+        }
+    }
+}
+
+template <typename IT>
+__global__ void __launch_bounds__(256)
+intensity_kernel(const IntensityParams p)
+{
+    constexpr int TL = sizeof(IT) == 8 ? 16 : 32;   // levels per index tile
+    constexpr int EPC = 16 / sizeof(IT);            // index elements per 16-byte chunk
+    constexpr int CPR = TL / EPC;                   // chunks per tile row
+    constexpr int RS = CPR + 1;                     // row stride in chunks (odd: conflict-free row reads)
+    typedef IT ITV __attribute__((ext_vector_type(EPC)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tab_bytes = ((p.LC * p.K * 2 + 15) & ~15);
+    _Float16 *tab = reinterpret_cast<_Float16 *>(smem_raw);                       // [LC][K]
+    float *wf = reinterpret_cast<float *>(smem_raw + tab_bytes);                   // [32] w, [32] wcum
+    unsigned *omask = reinterpret_cast<unsigned *>(wf + 64);                       // output levels of the tile
+    ITV *tiles = reinterpret_cast<ITV *>(smem_raw + tab_bytes + 64 * 4 + 16);      // [4 waves][64 rows][RS]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tokw = (long long)blockIdx.x * 256 + wave * 64;
+    const long long tok = tokw + lane;
+    ITV *tile = tiles + (size_t)wave * 64 * RS;
+    const IT *idx = reinterpret_cast<const IT *>(p.idx);
+
+    // this lane's share of the wave's tile: chunk c of row r for the CPR load steps
+    auto load_tile = [&](int m0, ITV (&regs)[CPR]) {
+#pragma unroll
+        for (int j = 0; j < CPR; ++j) {
+            const int u = j * 64 + lane, r = u / CPR, c = u % CPR;
+            long long t = tokw + r;
+            if (t >= p.n_tokens) t = p.n_tokens - 1;
+            const IT *src = idx + (size_t)t * p.nq + m0 + c * EPC;
+            if (p.vec_ok && m0 + TL <= p.nq) {
+                regs[j] = *reinterpret_cast<const ITV *>(src);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) regs[j][e] = (m0 + c * EPC + e < p.nq) ? src[e] : (IT)0;
+            }
+        }
+    };
+    ITV regs[CPR];
+    load_tile(0, regs);
+    float acc = 0.0f;
+
+    for (int m0 = 0; m0 < p.M; m0 += TL) {
+        __syncthreads();                                  // previous tile, table chunk and flags no longer read
+#pragma unroll
+        for (int j = 0; j < CPR; ++j) {
+            const int u = j * 64 + lane, r = u / CPR, c = u % CPR;
+            tile[r * RS + c] = regs[j];
+        }
+        if (threadIdx.x < TL) {
+            const int m = m0 + threadIdx.x;
+            wf[threadIdx.x] = m < p.M ? (float)p.w[m] : 0.0f;
+            wf[32 + threadIdx.x] = m < p.M ? (float)p.wcum[m] : 1.0f;
+        }
+        if (threadIdx.x == 0) *omask = 0u;
+        __syncthreads();
+        for (int j = threadIdx.x; j < p.n_layers; j += 256) {
+            const int l = p.layers[j];
+            if (l >= m0 && l < m0 + TL) atomicOr(omask, 1u << (l - m0));
+        }
+        if (m0 + TL < p.M) load_tile(m0 + TL, regs);      // next tile: in flight behind this one
+        for (int c0 = m0; c0 < m0 + TL && c0 < p.M; c0 += p.LC) {
+            if (c0 > m0) __syncthreads();                 // table chunk no longer read
+            const int nlev = (p.M - c0) < p.LC ? (p.M - c0) : p.LC;
+            const int n16 = (nlev * p.K * 2 + 15) / 16;   // whole 16-byte pieces (the table buffer is padded)
+            if ((((size_t)c0 * p.K * 2) & 15) == 0) {
+                const f4 *src = reinterpret_cast<const f4 *>(p.table + (size_t)c0 * p.K);
+                for (int u = threadIdx.x; u < n16; u += 256) reinterpret_cast<f4 *>(tab)[u] = src[u];
+            } else {                                      // odd K with a one- or two-level chunk
+                for (int u = threadIdx.x; u < nlev * p.K; u += 256) tab[u] = p.table[(size_t)c0 * p.K + u];
+            }
+            __syncthreads();
+            const unsigned mask = *omask;
+            int hi = c0 + p.LC;
+            if (hi > m0 + TL) hi = m0 + TL;
+            if (hi > p.M) hi = p.M;
+            for (int m = c0; m < hi; ++m) {
+                const int rel = m - m0;
+                const IT code = reinterpret_cast<const IT *>(tile + lane * RS)[rel];
+                const float sv = (float)tab[(m - c0) * p.K + (int)code];
+                const _Float16 prod = (_Float16)(sv * wf[rel]);            // sims *= layer_weights
+                acc += (float)prod;                                        // cumsum: fp32 accumulator
+                if ((mask >> rel) & 1u) {                                  // wave-uniform
+                    const _Float16 pref = (_Float16)acc;                   // ... prefixes rounded to fp16
+                    const _Float16 o = (_Float16)((float)pref / wf[32 + rel]);
+                    if (tok < p.n_tokens)
+                        for (int j = 0; j < p.n_layers; ++j)
+                            if (p.layers[j] == m) p.out[(size_t)tok * p.n_layers + j] = o;
+                }
+            }
+        }
+    }
+}
+
 struct PackedView {
     const Header *hdr;
     const float *w_in, *w_out, *b_out, *b_in, *cb, *rec_p, *cb_img;
@@ -2156,6 +2286,57 @@ int rqae_hip_gemma_denorm_patch(const float *q_out, const float *norm_weight, co
         hipLaunchKernelGGL(gemma_denorm_patch_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, s, q_out, norm_weight, inv_rms, (long long)n_tokens, d, seq_len, skip_bos, (float *)hs_inout, new_out);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int rqae_hip_intensity_prepare(const void *codebook_sims, const int *center, const void *layer_weights, int M, int K,
+                               void *table, void *wcum, void *stream)
+{
+    if (!codebook_sims || !center || !layer_weights || !table || !wcum) return fail("intensity_prepare: null pointer");
+    if (M < 1 || K < 1) return fail("intensity_prepare: bad sizes M=%d K=%d", M, K);
+    hipLaunchKernelGGL(intensity_prepare_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const _Float16 *)codebook_sims, center, (const _Float16 *)layer_weights, M, K,
+                       (_Float16 *)table, (_Float16 *)wcum);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rqae_hip_intensity(const void *table, const void *layer_weights, const void *wcum, int M, int K,
+                       const void *indices, int idx_dtype, int64_t n_tokens, int nq, const int *layers_dev,
+                       int n_layers, void *out, void *stream)
+{
+    if (!table || !layer_weights || !wcum || !indices || !layers_dev || !out) return fail("intensity: null pointer");
+    if (M < 1 || K < 1 || nq < M || n_layers < 1) return fail("intensity: bad sizes M=%d K=%d nq=%d n_layers=%d", M, K, nq, n_layers);
+    if (idx_dtype < RQAE_IDX_I64 || idx_dtype > RQAE_IDX_U16) return fail("intensity: bad idx_dtype %d", idx_dtype);
+    if (n_tokens < 0) return fail("intensity: negative n_tokens");
+    if (n_tokens == 0) return 0;
+    IntensityParams p;
+    p.table = (const _Float16 *)table; p.w = (const _Float16 *)layer_weights; p.wcum = (const _Float16 *)wcum;
+    p.idx = indices; p.layers = layers_dev; p.out = (_Float16 *)out;
+    p.n_tokens = n_tokens; p.nq = nq; p.M = M; p.K = K; p.n_layers = n_layers;
+    const size_t es = idx_dtype == RQAE_IDX_I64 ? 8 : idx_dtype == RQAE_IDX_I32 ? 4 : 2;
+    const int TL = es == 8 ? 16 : 32;
+    int LC = TL;
+    while (LC > 1 && (size_t)LC * K * 2 > 48 * 1024) LC >>= 1;
+    if ((size_t)LC * K * 2 > 96 * 1024) return fail("intensity: K=%d too large for the LDS table", K);
+    p.LC = LC;
+    p.vec_ok = (reinterpret_cast<uintptr_t>(indices) & 15) == 0 && ((size_t)nq * es) % 16 == 0 &&
+               (reinterpret_cast<uintptr_t>(table) & 15) == 0;
+    if ((reinterpret_cast<uintptr_t>(table) & 15) != 0) return fail("intensity: table must be 16-byte aligned");
+    const int RS = (int)(TL / (16 / es)) + 1;
+    const size_t lds = (((size_t)LC * K * 2 + 15) & ~(size_t)15) + 64 * 4 + 16 + (size_t)4 * 64 * RS * 16;
+    const long long nblk = (n_tokens + 255) / 256;
+    if (nblk > 0x7fffffffLL) return fail("intensity: too many tokens for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, p);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if (idx_dtype == RQAE_IDX_I64) return go(intensity_kernel<long long>);
+    if (idx_dtype == RQAE_IDX_I32) return go(intensity_kernel<int>);
+    return go(intensity_kernel<uint16_t>);
 }
 
 }  // extern "C"

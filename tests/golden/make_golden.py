@@ -169,8 +169,36 @@ def hook_case():
     print("hook_c2 written; patched dtype", out0.dtype)
 
 
+def feature_case():
+    """RQAEFeature.intensity (rqae/feature.py:102-129) on the pretrained shape's codebook (K = 625, c = 4)."""
+    from rqae.feature import RQAEFeature as RefFeature
+    cfg = dict(dim=256, codebook_dim=4, codebook_size=5, num_quantizers=48)
+    w = synth.weights(SEED_W, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = ref_model(cfg, w)
+    rng = np.random.Generator(np.random.PCG64(777))
+    L, K = cfg["num_quantizers"], m.codebook.shape[1]
+    center = rng.integers(0, K, size=L).astype(np.int32)
+    tok = rng.integers(0, K, size=(4, 32, L)).astype(np.int32)
+    layers = [0, 5, 17, L - 1]
+    feat = RefFeature.from_quantizer(m, center=center, layers=layers)
+    with torch.inference_mode():
+        out = feat.intensity(torch.from_numpy(tok), layers=layers)
+        out_default = RefFeature.from_quantizer(m, center=center).intensity(torch.from_numpy(tok))
+        out_sub = feat.intensity(torch.from_numpy(tok), layers=[3])
+    assert out.dtype == torch.float16
+    np.savez_compressed(
+        os.path.join(HERE, "feat_p.npz"),
+        meta=json.dumps(dict(cfg=cfg, seed_w=SEED_W, layers=layers)),
+        codebook_sims=m.codebook_sims.numpy(), layer_weights=feat.layer_weights.numpy(), center=center,
+        token_indices=tok, intensity=out.numpy(), intensity_default=out_default.numpy(), intensity_l3=out_sub.numpy())
+    print("feat_p written", out.shape, out.dtype, os.path.getsize(os.path.join(HERE, "feat_p.npz")))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "feature":
+        feature_case()
+        sys.exit(0)
     forward_case("fwd_c1", "C1", 4096, 1000)
     forward_case("fwd_c2", "C2", 4096, 1000)
     forward_case("fwd_c2_bf16", "C2", 2048, 1001, bf16=True)
@@ -182,3 +210,4 @@ if __name__ == "__main__":
     free_codebook_case("fwd_vq", 1024, 1007)
     kat_case()
     hook_case()
+    feature_case()

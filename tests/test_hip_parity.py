@@ -447,3 +447,63 @@ def test_gemma_norm_and_patch_kernels(d, dtype):
             new_o[:, 0] = hs_np[:, 0]
         assert np.array_equal(new.cpu().numpy(), new_o)
         assert torch.equal(h2, torch.from_numpy(new_o).to(dtype).to(DEV))
+
+
+# ------------------------------------------------------------------ RQAEFeature.intensity
+def _feature_setup(cfg, seed=1234, center=None, layers=None):
+    from rqae_amd import RQAEFeature
+    w = synth.weights(seed, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    return m, RQAEFeature.from_quantizer(m, center=center, layers=layers)
+
+
+def test_intensity_golden():
+    """The HIP kernel on the reference's own capture (feat_p fixture): its table, weights, codes -> its fp16 output."""
+    g = load_golden("feat_p")
+    cfg, layers = g["meta"]["cfg"], g["meta"]["layers"]
+    m, feat = _feature_setup(cfg, g["meta"]["seed_w"], center=g["center"], layers=layers)
+    # the fixture's table and weights (computed by the reference on the CPU) replace the device-computed ones
+    m.__dict__["_codebook_sims"] = torch.from_numpy(g["codebook_sims"]).to(DEV)
+    feat.layer_weights = torch.from_numpy(g["layer_weights"])
+    tok = torch.from_numpy(g["token_indices"])
+    for dtype in (torch.int32, torch.int64, torch.uint16):
+        out = feat.intensity(tok.to(dtype).to(DEV), layers=layers)
+        assert out.dtype == torch.float16 and out.shape == (4, 32, len(layers))
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), g["intensity"].view(np.uint16))
+    out = feat.intensity(tok, layers=[3])                       # CPU indices in, CPU result out
+    assert not out.is_cuda and np.array_equal(out.numpy().view(np.uint16), g["intensity_l3"].view(np.uint16))
+    from rqae_amd import RQAEFeature
+    f2 = RQAEFeature.from_quantizer(m, center=g["center"])      # default layers = [num_quantizers - 1]
+    f2.layer_weights = torch.from_numpy(g["layer_weights"])
+    out = f2.intensity(tok.to(DEV))
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), g["intensity_default"].view(np.uint16))
+
+
+@pytest.mark.parametrize("L,cbs,c,n,layers", [
+    (1024, 5, 4, 777, [0, 1, 31, 32, 33, 500, 1023, 500]),     # pretrained shape: K = 625, every level, duplicate column
+    (40, 4, 5, 1000, [39]),                                     # K = 1024: table chunk of 16 levels
+    (7, 2, 13, 300, [6, 0]),                                    # K = 8192: chunks of 2 levels
+    (3, 3, 2, 513, [2]),                                        # K = 9: odd K
+])
+def test_intensity_matches_oracle(L, cbs, c, n, layers):
+    """Shapes that exercise the tile / table-chunk / ragged paths, against the oracle bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(L * 131 + c))
+    K = cbs ** c
+    unit = rng.standard_normal((K, 4)).astype(np.float32)
+    unit /= np.linalg.norm(unit, axis=1, keepdims=True)
+    sims = (unit @ unit.T).astype(np.float16)
+    center = rng.integers(0, K, size=L).astype(np.int32)
+    lw = (0.5 + rng.random(L)).astype(np.float16)
+    tok = rng.integers(0, K, size=(n, L)).astype(np.int32)
+    from rqae_amd import _native as nat
+    M = max(layers) + 1
+    table, w, wcum = nat.intensity_prepare(torch.from_numpy(sims).to(DEV), torch.from_numpy(center), torch.from_numpy(lw), M)
+    want = oracle.intensity(sims, center, lw, tok, layers)
+    layers_dev = torch.tensor(layers, dtype=torch.int32, device=DEV)
+    for dtype in (torch.int32, torch.int64, torch.uint16):
+        out = nat.intensity(table, w, wcum, M, K, torch.from_numpy(tok).to(dtype).to(DEV), layers_dev)
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16)), dtype
+    # a view with an odd row length (no 16-byte rows): the scalar tile loads
+    tok_odd = np.concatenate([tok, np.zeros((n, 3), np.int32)], axis=1)
+    out = nat.intensity(table, w, wcum, M, K, torch.from_numpy(tok_odd).to(DEV), layers_dev)
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))

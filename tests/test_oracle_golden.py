@@ -135,3 +135,16 @@ def test_canonical_gemma_norm_against_reference_capture():
     new[:, 0] = h["hs"][:, 0].astype(np.float32)
     assert rel_err(new, h["new"]) < 1e-5
     assert (new.astype(np.float16) != h["patched"]).mean() < 1e-3      # fp16 write-back: at most a rare last-bit flip
+
+
+def test_intensity_against_reference_capture():
+    """the oracle's RQAEFeature.intensity restatement equals the reference's fp16 output bit for bit."""
+    g = load_golden("feat_p")
+    layers = g["meta"]["layers"]
+    L = g["center"].shape[0]
+    out = oracle.intensity(g["codebook_sims"], g["center"], g["layer_weights"], g["token_indices"], layers)
+    assert out.dtype == np.float16 and np.array_equal(out.view(np.uint16), g["intensity"].view(np.uint16))
+    out = oracle.intensity(g["codebook_sims"], g["center"], g["layer_weights"], g["token_indices"], [L - 1])
+    assert np.array_equal(out.view(np.uint16), g["intensity_default"].view(np.uint16))
+    out = oracle.intensity(g["codebook_sims"], g["center"], g["layer_weights"], g["token_indices"], [3])
+    assert np.array_equal(out.view(np.uint16), g["intensity_l3"].view(np.uint16))

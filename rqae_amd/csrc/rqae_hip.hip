@@ -1947,7 +1947,7 @@ template <typename IT>
 __global__ void __launch_bounds__(256)
 intensity_kernel(const IntensityParams p)
 {
-    constexpr int TL = sizeof(IT) == 8 ? 16 : 32;   // levels per index tile
+    constexpr int TL = 16;                          // levels per index tile
     constexpr int EPC = 16 / sizeof(IT);            // index elements per 16-byte chunk
     constexpr int CPR = TL / EPC;                   // chunks per tile row
     constexpr int RS = CPR + 1;                     // row stride in chunks (odd: conflict-free row reads)
@@ -1981,58 +1981,94 @@ intensity_kernel(const IntensityParams p)
             }
         }
     };
+    // table chunk [c0, c0+LC) -> registers (whole 16-byte pieces; at most 12 per thread for a 48-KiB chunk)
+    constexpr int TPT = 12;
+    auto load_table = [&](int c0, f4 (&tregs)[TPT]) {
+        const int nlev = (p.M - c0) < p.LC ? (p.M - c0) : p.LC;
+        const int n16 = (nlev * p.K * 2 + 15) / 16;
+        const f4 *src = reinterpret_cast<const f4 *>(p.table + (size_t)c0 * p.K);
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            const int u = j * 256 + threadIdx.x;
+            if (u < n16) tregs[j] = src[u];
+        }
+    };
     ITV regs[CPR];
+    f4 tregs[TPT];
     load_tile(0, regs);
+    load_table(0, tregs);
     float acc = 0.0f;
 
-    for (int m0 = 0; m0 < p.M; m0 += TL) {
-        __syncthreads();                                  // previous tile, table chunk and flags no longer read
+    for (int c0 = 0; c0 < p.M; c0 += p.LC) {
+        const int m0 = c0 & ~(TL - 1);
+        const bool new_tile = c0 == m0;
+        __syncthreads();                                  // previous table chunk (and tile) no longer read
+        if (new_tile) {
 #pragma unroll
-        for (int j = 0; j < CPR; ++j) {
-            const int u = j * 64 + lane, r = u / CPR, c = u % CPR;
-            tile[r * RS + c] = regs[j];
-        }
-        if (threadIdx.x < TL) {
-            const int m = m0 + threadIdx.x;
-            wf[threadIdx.x] = m < p.M ? (float)p.w[m] : 0.0f;
-            wf[32 + threadIdx.x] = m < p.M ? (float)p.wcum[m] : 1.0f;
-        }
-        if (threadIdx.x == 0) *omask = 0u;
-        __syncthreads();
-        for (int j = threadIdx.x; j < p.n_layers; j += 256) {
-            const int l = p.layers[j];
-            if (l >= m0 && l < m0 + TL) atomicOr(omask, 1u << (l - m0));
-        }
-        if (m0 + TL < p.M) load_tile(m0 + TL, regs);      // next tile: in flight behind this one
-        for (int c0 = m0; c0 < m0 + TL && c0 < p.M; c0 += p.LC) {
-            if (c0 > m0) __syncthreads();                 // table chunk no longer read
-            const int nlev = (p.M - c0) < p.LC ? (p.M - c0) : p.LC;
-            const int n16 = (nlev * p.K * 2 + 15) / 16;   // whole 16-byte pieces (the table buffer is padded)
-            if ((((size_t)c0 * p.K * 2) & 15) == 0) {
-                const f4 *src = reinterpret_cast<const f4 *>(p.table + (size_t)c0 * p.K);
-                for (int u = threadIdx.x; u < n16; u += 256) reinterpret_cast<f4 *>(tab)[u] = src[u];
-            } else {                                      // odd K with a one- or two-level chunk
-                for (int u = threadIdx.x; u < nlev * p.K; u += 256) tab[u] = p.table[(size_t)c0 * p.K + u];
+            for (int j = 0; j < CPR; ++j) {
+                const int u = j * 64 + lane, r = u / CPR, c = u % CPR;
+                tile[r * RS + c] = regs[j];
             }
-            __syncthreads();
-            const unsigned mask = *omask;
-            int hi = c0 + p.LC;
-            if (hi > m0 + TL) hi = m0 + TL;
-            if (hi > p.M) hi = p.M;
-            for (int m = c0; m < hi; ++m) {
-                const int rel = m - m0;
-                const IT code = reinterpret_cast<const IT *>(tile + lane * RS)[rel];
-                const float sv = (float)tab[(m - c0) * p.K + (int)code];
-                const _Float16 prod = (_Float16)(sv * wf[rel]);            // sims *= layer_weights
-                acc += (float)prod;                                        // cumsum: fp32 accumulator
-                if ((mask >> rel) & 1u) {                                  // wave-uniform
-                    const _Float16 pref = (_Float16)acc;                   // ... prefixes rounded to fp16
-                    const _Float16 o = (_Float16)((float)pref / wf[32 + rel]);
-                    if (tok < p.n_tokens)
-                        for (int j = 0; j < p.n_layers; ++j)
-                            if (p.layers[j] == m) p.out[(size_t)tok * p.n_layers + j] = o;
+            if (threadIdx.x < 64) {                       // weights of the tile's levels; which of them are outputs
+                const int m = m0 + threadIdx.x;
+                bool hit = false;
+                if (threadIdx.x < TL) {
+                    wf[threadIdx.x] = m < p.M ? (float)p.w[m] : 0.0f;
+                    wf[32 + threadIdx.x] = m < p.M ? (float)p.wcum[m] : 1.0f;
+                    for (int j = 0; j < p.n_layers; ++j) hit |= p.layers[j] == m;
                 }
+                const unsigned long long b = __ballot(hit);
+                if (threadIdx.x == 0) *omask = (unsigned)b;
             }
+        }
+        {
+            const int nlev = (p.M - c0) < p.LC ? (p.M - c0) : p.LC;
+            const int n16 = (nlev * p.K * 2 + 15) / 16;
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) {
+                const int u = j * 256 + threadIdx.x;
+                if (u < n16) reinterpret_cast<f4 *>(tab)[u] = tregs[j];
+            }
+        }
+        __syncthreads();
+        if (c0 + p.LC < p.M) {                            // next chunk (and tile): in flight behind this one
+            load_table(c0 + p.LC, tregs);
+            if (((c0 + p.LC) & (TL - 1)) == 0) load_tile(c0 + p.LC, regs);
+        }
+        const unsigned mask = *omask;
+        int hi = c0 + p.LC;
+        if (hi > p.M) hi = p.M;
+        auto emit = [&](int m, int rel) __attribute__((always_inline)) {   // output level: wave-uniform branch
+            const _Float16 pref = (_Float16)acc;                              // cumsum's prefixes are fp16
+            const _Float16 o = (_Float16)((float)pref / wf[32 + rel]);
+            if (tok < p.n_tokens)
+                for (int j = 0; j < p.n_layers; ++j)
+                    if (p.layers[j] == m) p.out[(size_t)tok * p.n_layers + j] = o;
+        };
+        int m = c0;
+        // whole 16-byte groups of codes: one row read, EPC gathers in flight together, then the sequential sum
+        for (; m + EPC <= hi && ((m - m0) % EPC) == 0; m += EPC) {
+            const int rel = m - m0;
+            const ITV codes = tile[lane * RS + rel / EPC];
+            float sv[EPC], wv[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sv[e] = (float)tab[(m + e - c0) * p.K + (int)codes[e]];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) wv[e] = wf[rel + e];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const _Float16 prod = (_Float16)(sv[e] * wv[e]);             // sims *= layer_weights
+                acc += (float)prod;                                            // cumsum: fp32 accumulator
+                if ((mask >> (rel + e)) & 1u) emit(m + e, rel + e);
+            }
+        }
+        for (; m < hi; ++m) {
+            const int rel = m - m0;
+            const IT code = reinterpret_cast<const IT *>(tile + lane * RS)[rel];
+            const float sv = (float)tab[(m - c0) * p.K + (int)code];
+            const _Float16 prod = (_Float16)(sv * wf[rel]);
+            acc += (float)prod;
+            if ((mask >> rel) & 1u) emit(m, rel);
         }
     }
 }
@@ -2314,10 +2350,11 @@ int rqae_hip_intensity(const void *table, const void *layer_weights, const void 
     p.idx = indices; p.layers = layers_dev; p.out = (_Float16 *)out;
     p.n_tokens = n_tokens; p.nq = nq; p.M = M; p.K = K; p.n_layers = n_layers;
     const size_t es = idx_dtype == RQAE_IDX_I64 ? 8 : idx_dtype == RQAE_IDX_I32 ? 4 : 2;
-    const int TL = es == 8 ? 16 : 32;
+    const int TL = 16;
     int LC = TL;
     while (LC > 1 && (size_t)LC * K * 2 > 48 * 1024) LC >>= 1;
-    if ((size_t)LC * K * 2 > 96 * 1024) return fail("intensity: K=%d too large for the LDS table", K);
+    if ((size_t)LC * K * 2 > 48 * 1024) return fail("intensity: K=%d too large for the LDS table", K);
+    if (((size_t)LC * K * 2) % 16 != 0) return fail("intensity: K=%d needs LC*K*2 %% 16 == 0 (LC=%d)", K, LC);
     p.LC = LC;
     p.vec_ok = (reinterpret_cast<uintptr_t>(indices) & 15) == 0 && ((size_t)nq * es) % 16 == 0 &&
                (reinterpret_cast<uintptr_t>(table) & 15) == 0;

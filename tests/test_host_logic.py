@@ -104,3 +104,31 @@ def test_hook_argument_protocol():
     with pytest.raises(AssertionError):
         m.hook(llm=object())
     assert callable(m.hook(norm=lambda a: a, denorm=lambda a, b: a))
+
+
+def test_feature_mirror_host_side():
+    """rqae_amd.RQAEFeature keeps the reference's constructor defaults, attributes and error behaviour
+    (rqae/feature.py:42-137); the kernel itself is covered by the gpu tests."""
+    import pickle
+
+    import numpy as np
+    import torch
+
+    from rqae_amd import RQAE, Feature, RQAEFeature
+
+    f = RQAEFeature(num_quantizers=6, dim=4)
+    assert f.layers == [5] and f.center.dtype == torch.int32 and f.center.shape == (6,)
+    assert f.layer_weights.shape == (6,) and f.explanations == [""] and f.scores == [{}] and f.activations == {5: []}
+    with pytest.raises(ValueError):
+        f.intensity(torch.zeros(2, 6, dtype=torch.int32))          # "Model not loaded"
+    m = RQAE(dim=64, codebook_dim=2, codebook_size=3, num_quantizers=6).eval()
+    g = RQAEFeature.from_quantizer(m, center=np.arange(6) % 9, layers=[1, 5])
+    assert g.num_quantizers == 6 and g.dim == 2 and g.layer_weights.dtype == torch.float16
+    want = torch.tensor([l[1].weight.data.norm(dim=0).mean().item() for l in m.layers]).to(torch.float16)
+    assert torch.equal(g.layer_weights, want)
+    with pytest.raises(RuntimeError):
+        g.intensity(torch.zeros(2, 6, dtype=torch.int32))          # CPU-resident model: no CPU path
+    h = pickle.loads(pickle.dumps(g))
+    assert h.layers == [1, 5] and torch.equal(h.center, g.center) and h._prepared is None
+    t = g.to_feature(1)
+    assert isinstance(t, Feature) and t.activations == []

@@ -1637,7 +1637,17 @@ rqae_decode_lds_kernel(const DecParams p)
         }
         dma_wait_all();
         __syncthreads();                                      // weights of level l + codebook values visible
-        if (ln < p.nlev) issue_dma(ln, buf ^ 1);              // next selected level loads behind this one
+        // next selected level loads behind this one: one piece per element step (a burst of all pieces waits
+        // on the TA's address queue, see the encode kernel)
+        int dpc = ln < p.nlev ? wave : NSLICE * QD;
+        const float *drec = p.rec_p + (size_t)(ln + 1) * NSLICE * NQ * 256;
+        auto dma_step = [&]() __attribute__((always_inline)) {
+            if (dpc < NSLICE * QD) {
+                const int s = dpc / QD, q = dpc - s * QD;
+                dma_pieces<1>(drec + (size_t)(s * NQ + q) * 256, wbuf_addr + ((buf ^ 1) * BUF + dpc * 256) * 4, lane * 16);
+                dpc += NW;
+            }
+        };
 
         const f4 *wl = reinterpret_cast<const f4 *>(wbuf + buf * BUF) + (size_t)slice * QD * 64 + lane;
         const float *cvp = cvl + (l - staged_from) * C * TG + half * TPW;
@@ -1662,6 +1672,7 @@ rqae_decode_lds_kernel(const DecParams p)
 #pragma unroll
             for (int q = 0; q < QD; ++q)
                 if (i + 1 < P && q > last_quad_of_step(i, W) && q <= last_quad_of_step(i + 1, W)) wq[q] = wl[q * 64];
+            dma_step();
             f2 yy[NG][2];   // the four chains interleaved, as in the encode kernel's sweep 1
 #pragma unroll
             for (int k = 0; k < C; ++k)
@@ -1679,6 +1690,7 @@ rqae_decode_lds_kernel(const DecParams p)
                     else acc[i][2 * g + pr] = acc[i][2 * g + pr] + yy[g][pr];
                 }
         }
+        while (dpc < NSLICE * QD) dma_step();                 // more pieces per wave than element steps
         first = false;
         l = ln;
         buf ^= 1;

@@ -507,3 +507,31 @@ def test_intensity_matches_oracle(L, cbs, c, n, layers):
     tok_odd = np.concatenate([tok, np.zeros((n, 3), np.int32)], axis=1)
     out = nat.intensity(table, w, wcum, M, K, torch.from_numpy(tok_odd).to(DEV), layers_dev)
     assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+def test_forward_and_decode_capture_into_a_hip_graph():
+    """The C ABI only enqueues work on the given stream (no sync, no allocation, no host-side state per call),
+    so a forward + decode pair can be captured once and replayed -- the launch-bound small-batch case
+    (64 x 128 tokens = 0.12 ms of kernel) of a serving loop."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    x = torch.from_numpy(synth.activations(9, 512, cfg["dim"])).to(DEV).view(4, 128, -1)
+    with torch.inference_mode():
+        q_ref, idx_ref = m(x)                      # also builds the packed weight block outside the capture
+        d_ref = m.decode(idx_ref)
+        torch.cuda.synchronize()
+        static_x = x.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            q, idx = m(static_x)
+            d = m.decode(idx)
+        static_x.copy_(torch.flip(x, dims=[1]))   # new input, same buffers
+        g.replay()
+        torch.cuda.synchronize()
+        q2, idx2 = m(torch.flip(x, dims=[1]))
+        assert torch.equal(idx, idx2) and torch.equal(q, q2) and torch.equal(d, m.decode(idx2))
+        static_x.copy_(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(idx, idx_ref) and torch.equal(q, q_ref) and torch.equal(d, d_ref)

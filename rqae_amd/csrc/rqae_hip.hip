@@ -1570,8 +1570,11 @@ int launch_decode(const DecParams &p, bool from_idx, hipStream_t stream)
 // lin_out weights of a level are the first two quads of every element step of pass record l+1
 // (w_out[0..c-1], b_out), copied L2 -> LDS by LDS-DMA into one of TWO buffers, so level l+1 loads while
 // level l computes.  Codebook values of the tile (16 tokens x 32 levels x c) are gathered into LDS.
-template <int P, int C, bool FROM_IDX>
-__global__ void __launch_bounds__(512, 2)
+// NBUF = 2: the next level's weights load into a second LDS buffer behind the current level (one workgroup per CU).
+// NBUF = 1: one buffer, 66 KB of LDS and <= 128 VGPRs, so TWO workgroups share a CU and cover each other's load and
+//           barrier waits (the kernel is VALU-bound once those are hidden).
+template <int P, int C, bool FROM_IDX, int NBUF>
+__global__ void __launch_bounds__(512, NBUF == 1 ? 4 : 2)
 rqae_decode_lds_kernel(const DecParams p)
 {
     constexpr int TPW = 8, NW = 8, TG = 16, NPAIR = 4, NG = 2, LCH = 32;
@@ -1582,8 +1585,8 @@ rqae_decode_lds_kernel(const DecParams p)
     constexpr int dp = 256 * P;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wbuf = smem;                          // [2][slice][QD][lane][4]
-    float *cvl = wbuf + 2 * BUF;                 // [LCH][C][TG]  (token pairs contiguous)
+    float *wbuf = smem;                          // [NBUF][slice][QD][lane][4]
+    float *cvl = wbuf + NBUF * BUF;                 // [LCH][C][TG]  (token pairs contiguous)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1614,8 +1617,16 @@ rqae_decode_lds_kernel(const DecParams p)
     int l = next_on(0), buf = 0;
     if (l < p.nlev) issue_dma(l, 0);
     int staged_from = -1;                         // first level of the codebook-value chunk in LDS
+    bool first_level = true;
     while (l < p.nlev) {
         const int ln = next_on(l + 1);
+        if constexpr (NBUF == 1) {
+            if (!first_level) {
+                __syncthreads();                              // every wave is done with the previous level's weights
+                issue_dma(l, 0);
+            }
+            first_level = false;
+        }
         if (l >= staged_from + LCH || staged_from < 0) {
             // gather this tile's codebook values for levels [l, l+LCH)
             if (staged_from >= 0) __syncthreads();            // previous chunk no longer read
@@ -1639,7 +1650,7 @@ rqae_decode_lds_kernel(const DecParams p)
         __syncthreads();                                      // weights of level l + codebook values visible
         // next selected level loads behind this one: one piece per element step (a burst of all pieces waits
         // on the TA's address queue, see the encode kernel)
-        int dpc = ln < p.nlev ? wave : NSLICE * QD;
+        int dpc = (NBUF == 2 && ln < p.nlev) ? wave : NSLICE * QD;
         const float *drec = p.rec_p + (size_t)(ln + 1) * NSLICE * NQ * 256;
         auto dma_step = [&]() __attribute__((always_inline)) {
             if (dpc < NSLICE * QD) {
@@ -1693,7 +1704,7 @@ rqae_decode_lds_kernel(const DecParams p)
         while (dpc < NSLICE * QD) dma_step();                 // more pieces per wave than element steps
         first = false;
         l = ln;
-        buf ^= 1;
+        if constexpr (NBUF == 2) buf ^= 1;
     }
 
 #pragma unroll
@@ -1716,7 +1727,9 @@ template <int P, int C>
 int launch_decode_lds(const DecParams &p, bool from_idx, hipStream_t stream)
 {
     constexpr int QD = rec_out_quads(P, C);
-    const size_t lds = sizeof(float) * (2 * (size_t)NSLICE * QD * 256 + 32 * C * 16);
+    const char *nb = getenv("RQAE_HIP_DECODE_NBUF");     // 2 = the double-buffered form (measured slower: 1.42 vs 1.16 ms)
+    const int nbuf = nb && atoi(nb) == 2 ? 2 : 1;
+    const size_t lds = sizeof(float) * ((size_t)nbuf * NSLICE * QD * 256 + 32 * C * 16);
     const long long nblk = (p.n_tokens + 15) / 16;
     if (nblk > 0x7fffffffLL) return fail("decode: too many tokens for one launch");
     auto go = [&](auto kern) -> int {
@@ -1727,8 +1740,12 @@ int launch_decode_lds(const DecParams &p, bool from_idx, hipStream_t stream)
         HIP_TRY(hipGetLastError());
         return 0;
     };
-    if (from_idx) return go(rqae_decode_lds_kernel<P, C, true>);
-    return go(rqae_decode_lds_kernel<P, C, false>);
+    if (nbuf == 2) {
+        if (from_idx) return go(rqae_decode_lds_kernel<P, C, true, 2>);
+        return go(rqae_decode_lds_kernel<P, C, false, 2>);
+    }
+    if (from_idx) return go(rqae_decode_lds_kernel<P, C, true, 1>);
+    return go(rqae_decode_lds_kernel<P, C, false, 1>);
 }
 
 int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t stream)

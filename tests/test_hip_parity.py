@@ -509,6 +509,24 @@ def test_intensity_matches_oracle(L, cbs, c, n, layers):
     assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
 
 
+def test_decode_double_buffered_form(monkeypatch):
+    """RQAE_HIP_DECODE_NBUF=2 selects the double-buffered decode kernel (one workgroup per CU): same bits."""
+    g = load_golden("fwd_c2")
+    cfg, w, _ = case_inputs(g)
+    m = make_model(cfg, w)
+    idx = torch.from_numpy(g["codes"].astype(np.int64)).to(DEV).view(1, -1, g["codes"].shape[-1])
+    with torch.inference_mode():
+        d1 = m.decode(idx)
+        monkeypatch.setenv("RQAE_HIP_DECODE_NBUF", "2")
+        d2 = m.decode(idx)
+        d3 = m.decode(idx, layers=[0, 2])
+        monkeypatch.delenv("RQAE_HIP_DECODE_NBUF")
+        d4 = m.decode(idx, layers=[0, 2])
+    assert torch.equal(d1, d2) and torch.equal(d3, d4)
+    assert np.array_equal(d1[0].cpu().numpy()[g["rows"]], g["dec_rows"])
+    assert np.array_equal(d3[0].cpu().numpy()[g["rows"]], g["dec02_rows"])
+
+
 def test_forward_and_decode_capture_into_a_hip_graph():
     """The C ABI only enqueues work on the given stream (no sync, no allocation, no host-side state per call),
     so a forward + decode pair can be captured once and replayed -- the launch-bound small-batch case

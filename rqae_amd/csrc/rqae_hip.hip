@@ -4,6 +4,8 @@
 //   rqae_hip_encode         RQAE.forward level loop            rqae/model.py:199-230
 //   rqae_hip_quantize       RQAE.quantize at temperature 0     rqae/model.py:187-197
 //   rqae_hip_decode[_values] RQAE.decode                       rqae/model.py:232-252
+//   rqae_hip_gemma_norm / _denorm_patch   the steps either side of forward in RQAE.hook   rqae/model.py:276-289
+//   rqae_hip_intensity[_prepare]          RQAEFeature.intensity                             rqae/feature.py:102-129
 //
 // Arithmetic contract (restated on the CPU by
 // oracle/rqae_oracle.c, which these kernels match bit for bit):
@@ -19,11 +21,15 @@
 //   * cos-sim : k-ordered fmaf chain from +0; argmax = first maximum
 //   * STE     : q + (cv - q);  lin_out: k-ordered fmaf chain from +0, then + bias
 //
-// Work decomposition of the encode kernel: one workgroup owns TG tokens for all
+// Work decomposition of the encode kernels: one workgroup owns TG tokens for all
 // levels.  Wave (slice, half) keeps the residual and the running reconstruction of
 // its TPW tokens x 64*P elements in VGPRs for the whole level loop (the N x d
 // residual never goes back to HBM); weights stream from L2 once per level per
-// workgroup; the only exchange per level is c floats per token through LDS.
+// workgroup (LDS-DMA into LDS in rqae_encode_lds_kernel, the main path); the only
+// exchange per level is 4c partial sums in and c floats out per token through LDS.
+// Kernels, in file order: pack; rqae_encode_kernel (generic shapes); rqae_encode_lds_kernel
+// (main); rqae_quantize_kernel; rqae_decode_kernel / rqae_decode_lds_kernel; the hook
+// kernels; intensity.  DESIGN.md section 5 describes each with its roofline.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdarg.h>

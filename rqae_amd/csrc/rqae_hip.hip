@@ -1414,9 +1414,13 @@ struct QuantParams {
     float *cv;
     long long *idx;
     long long n;
-    int c, K, kch;
+    int c, K, kch, iters;
 };
 
+// One workgroup = 4 waves; a wave quantises TQ tokens at a time.  When the codebook fits in LDS in one chunk it is
+// staged once per workgroup and the waves walk `iters` token groups against it (staging 20 KB per 16 tokens was
+// 25x the algorithmic bytes); a chunked codebook keeps one group per workgroup (the running maxima of a group
+// live in registers across the chunks).
 template <int C>
 __global__ void __launch_bounds__(256)
 rqae_quantize_kernel(const QuantParams p)
@@ -1426,36 +1430,47 @@ rqae_quantize_kernel(const QuantParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cp = p.c;
-    const long long tokw = ((long long)blockIdx.x * 4 + wave) * TQ;
-    float q[TQ][C], xn[TQ][C], best[TQ];
-    int bidx[TQ];
-#pragma unroll
-    for (int tq = 0; tq < TQ; ++tq) {
-        const long long tok = tokw + tq;
-#pragma unroll
-        for (int j = 0; j < C; ++j) q[tq][j] = (j < cp && tok < p.n) ? p.p[tok * cp + j] : 0.0f;
-        const float nrm = aten_norm2<C>(q[tq], cp);
-#pragma unroll
-        for (int j = 0; j < C; ++j) xn[tq][j] = q[tq][j] / nrm;
-        best[tq] = -INFINITY;
-        bidx[tq] = 0;
-    }
     const int nchunk = (p.K + p.kch - 1) / p.kch;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int row_base = ch * p.kch;
-        const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
-        if (ch > 0) __syncthreads();
-        stage_floats(smem, p.cb + (size_t)row_base * cp, rows * cp);
+    if (nchunk == 1) {
+        stage_floats(smem, p.cb, p.K * cp);
         __syncthreads();
-        scan_rows<C, TQ>(xn, smem, rows, row_base, cp, lane, best, bidx);
     }
+    for (int it = 0; it < p.iters; ++it) {
+        const long long tokw = (((long long)blockIdx.x * p.iters + it) * 4 + wave) * TQ;
+        if (nchunk == 1 && tokw >= p.n) break;                // wave-uniform; (a chunked codebook has barriers below: every wave stays)
+        float q[TQ][C], xn[TQ][C], best[TQ];
+        int bidx[TQ];
 #pragma unroll
-    for (int tq = 0; tq < TQ; ++tq) {
-        wave_argmax(best[tq], bidx[tq]);
-        const long long tok = tokw + tq;
-        if (tok < p.n) {
-            if (lane == 0) p.idx[tok] = bidx[tq];
-            if (lane < cp) p.cv[tok * cp + lane] = p.cb[(size_t)bidx[tq] * cp + lane];
+        for (int tq = 0; tq < TQ; ++tq) {
+            const long long tok = tokw + tq;
+#pragma unroll
+            for (int j = 0; j < C; ++j) q[tq][j] = (j < cp && tok < p.n) ? p.p[tok * cp + j] : 0.0f;
+            const float nrm = aten_norm2<C>(q[tq], cp);
+#pragma unroll
+            for (int j = 0; j < C; ++j) xn[tq][j] = q[tq][j] / nrm;
+            best[tq] = -INFINITY;
+            bidx[tq] = 0;
+        }
+        if (nchunk == 1) {
+            scan_rows<C, TQ>(xn, smem, p.K, 0, cp, lane, best, bidx);
+        } else {
+            for (int ch = 0; ch < nchunk; ++ch) {             // iters == 1 here: every wave of the block takes part
+                const int row_base = ch * p.kch;
+                const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
+                if (ch > 0) __syncthreads();
+                stage_floats(smem, p.cb + (size_t)row_base * cp, rows * cp);
+                __syncthreads();
+                scan_rows<C, TQ>(xn, smem, rows, row_base, cp, lane, best, bidx);
+            }
+        }
+#pragma unroll
+        for (int tq = 0; tq < TQ; ++tq) {
+            wave_argmax(best[tq], bidx[tq]);
+            const long long tok = tokw + tq;
+            if (tok < p.n) {
+                if (lane == 0) p.idx[tok] = bidx[tq];
+                if (lane < cp) p.cv[tok * cp + lane] = p.cb[(size_t)bidx[tq] * cp + lane];
+            }
         }
     }
 }
@@ -2260,7 +2275,14 @@ int rqae_hip_quantize(const float *pin, int64_t n, int c, int K, const float *co
     p.kch = kch;
     const int rows = kch < K ? kch : K;
     const size_t lds = sizeof(float) * (size_t)rows * c;
-    const long long nblk = (n + 15) / 16;
+    // token groups per workgroup: enough workgroups to fill the chip several times over, at most 16 groups each
+    int iters = 1;
+    if (kch >= K) {
+        const long long groups = (n + 15) / 16;
+        while (iters < 16 && groups / (iters * 2) >= 256 * 8) iters *= 2;
+    }
+    p.iters = iters;
+    const long long nblk = (n + 16LL * iters - 1) / (16LL * iters);
     if (nblk > 0x7fffffffLL) return fail("quantize: too many rows for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
     auto go = [&](auto kern) -> int {

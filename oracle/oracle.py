@@ -169,22 +169,39 @@ def _lane_tree(v):
     return ((u[..., 0] + u[..., 1]).astype(np.float32) + (u[..., 2] + u[..., 3]).astype(np.float32)).astype(np.float32)
 
 
+def _elem_of(P, s, i, lane):
+    """oracle/rqae_oracle.c:elem_of: element of (slice s, step i, lane)."""
+    base = s * 64 * P
+    q4 = (P // 4) * 4
+    if i < q4:
+        return base + 256 * (i // 4) + 4 * lane + (i % 4)
+    rem, j = P - q4, i - q4
+    if rem >= 2 and j < 2:
+        return base + 64 * q4 + 2 * lane + j
+    return base + 64 * q4 + (128 if rem >= 2 else 0) + lane
+
+
 def gemma_norm_canonical(hs, weight, eps=1e-6):
-    """rqae_hip_gemma_norm restated: lane owns elements 4*(lane + 64*j) + {0..3}, fma chain of squares per
-    lane, lane tree, / d, rs = 1/sqrt(ms + eps); normed = (x * rs) * (1 + w).  Returns (normed, rs)."""
+    """rqae_hip_gemma_norm (and the norm folded into rqae_hip_encode_gemma) restated.  The row sum of squares
+    uses the canonical order of DESIGN.md section 3, the one lin_in uses: d zero-padded to 256*P, 4 slices,
+    per (slice, lane) an fma chain over the element steps from +0, the 64-lane tree, slices as
+    (s0+s1)+(s2+s3); then / d, rs = 1/sqrt(ms + eps), normed = (x * rs) * (1 + w).  Returns (normed, rs)."""
     x = np.asarray(hs).astype(np.float32)
     lead, d = x.shape[:-1], x.shape[-1]
     x2 = x.reshape(-1, d)
     n = x2.shape[0]
-    dp = ((d + 255) // 256) * 256
-    xp = np.zeros((n, dp), np.float32); xp[:, :d] = x2
-    blocks = xp.reshape(n, dp // 256, 64, 4)           # [token][j][lane][u]
-    ss = np.zeros((n, 64), np.float32)
-    for j in range(dp // 256):
-        for u in range(4):
-            v = blocks[:, j, :, u]
+    P = (d + 255) // 256
+    xp = np.zeros((n, 256 * P), np.float32)
+    xp[:, :d] = x2
+    lanes = np.arange(64)
+    tot = []
+    for s in range(4):
+        ss = np.zeros((n, 64), np.float32)
+        for i in range(P):
+            v = xp[:, [_elem_of(P, s, i, int(l)) for l in lanes]]
             ss = (v.astype(np.float64) * v.astype(np.float64) + ss.astype(np.float64)).astype(np.float32)
-    total = _lane_tree(ss)
+        tot.append(_lane_tree(ss))
+    total = ((tot[0] + tot[1]).astype(np.float32) + (tot[2] + tot[3]).astype(np.float32)).astype(np.float32)
     ms = (total / np.float32(d)).astype(np.float32)
     rs = (np.float32(1.0) / np.sqrt((ms + np.float32(eps)).astype(np.float32))).astype(np.float32)
     w1 = (np.float32(1.0) + np.asarray(weight, np.float32)).astype(np.float32)

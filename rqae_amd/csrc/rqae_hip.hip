@@ -1805,6 +1805,18 @@ __device__ __forceinline__ float wave_tree_sum(float v, int lane)
     return fin[0];
 }
 
+// Sum of the four slice totals of every lane's value (in: per-lane partial of slice s in ss[s]) in the order of
+// section 3: the 64-lane tree per slice, then (s0+s1)+(s2+s3).  Every lane returns the row total.
+__device__ __forceinline__ float canonical_row_total(const float (&ss)[NSLICE], int lane)
+{
+    float fin[1];
+    ReduceScatter<NSLICE, 0, 1>::run(ss, fin, lane);      // lane holds the tree sum of slice (bit5 + 2*bit4)
+    const float s0 = lane_bcast(fin[0], 0), s1 = lane_bcast(fin[0], 32);
+    const float s2 = lane_bcast(fin[0], 16), s3 = lane_bcast(fin[0], 48);
+    return (s0 + s1) + (s2 + s3);
+}
+
+// One wave per token, any d (runtime P = ceil(d / 256)), scalar loads.
 template <typename HT>
 __global__ void __launch_bounds__(256)
 gemma_norm_kernel(const HT *hs, const float *w, float eps, long long n_tokens, int d, float *normed, float *rs_out)
@@ -1812,74 +1824,62 @@ gemma_norm_kernel(const HT *hs, const float *w, float eps, long long n_tokens, i
     const int lane = threadIdx.x & 63;
     const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= n_tokens) return;
+    const int P = (d + 255) / 256;
     const HT *row = hs + (size_t)tok * d;
-    float ss = 0.0f;
-    for (int e0 = 4 * lane; e0 < d; e0 += 256) {
+    float ss[NSLICE];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e0 + u < d) { const float x = widen<HT>(row[e0 + u]); ss = fmaf(x, x, ss); }
+    for (int s = 0; s < NSLICE; ++s) {
+        float a = 0.0f;
+        for (int i = 0; i < P; ++i) {
+            const int e = elem_of(P, s, i, lane);
+            const float x = e < d ? widen<HT>(row[e]) : 0.0f;
+            a = fmaf(x, x, a);
+        }
+        ss[s] = a;
     }
-    const float total = wave_tree_sum(ss, lane);
+    const float total = canonical_row_total(ss, lane);
     const float ms = total / (float)d;
     const float rs = 1.0f / __builtin_sqrtf(ms + eps);
     if (lane == 0) rs_out[tok] = rs;
     float *orow = normed + (size_t)tok * d;
-    for (int e0 = 4 * lane; e0 < d; e0 += 256) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e0 + u < d) {
-                const float x = widen<HT>(row[e0 + u]);
-                const float t = x * rs;
-                orow[e0 + u] = t * (1.0f + w[e0 + u]);
-            }
+    for (int e = lane; e < d; e += 64) {
+        const float t = widen<HT>(row[e]) * rs;
+        orow[e] = t * (1.0f + w[e]);
     }
 }
 
-// Vector form for d % 4 == 0, d <= 1024*NJ, 16-byte aligned rows: hs is read ONCE (4 elements = one 8-byte
-// or 16-byte load per lane and step, kept in registers across the reduction) and normed written as float4.
-// Same arithmetic and order as gemma_norm_kernel.
-template <typename HT, int NJ>
+// Vector form for d == 256 * P with 16-byte aligned rows: hs is read ONCE with the tile loads of the encode
+// kernel (runs of 4 / 2 / 1 consecutive elements per lane), kept in registers across the reduction, and normed
+// is written with the matching vector stores.  Same arithmetic and order as gemma_norm_kernel.
+template <typename HT, int P>
 __global__ void __launch_bounds__(256)
 gemma_norm_vec_kernel(const HT *hs, const float *w, float eps, long long n_tokens, int d, float *normed, float *rs_out)
 {
-    typedef typename VecOf<HT, 4>::type H4;
     const int lane = threadIdx.x & 63;
     const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= n_tokens) return;
-    const HT *row = hs + (size_t)tok * d;
-    float x[NJ][4];
+    float x[NSLICE][P][1];
+    float ss[NSLICE];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int e0 = 4 * (lane + 64 * j);
-        if (e0 < d) {
-            const H4 v = *reinterpret_cast<const H4 *>(row + e0);
-            x[j][0] = widen<HT>(v.x); x[j][1] = widen<HT>(v.y); x[j][2] = widen<HT>(v.z); x[j][3] = widen<HT>(v.w);
-        } else {
-            x[j][0] = x[j][1] = x[j][2] = x[j][3] = 0.0f;
-        }
+    for (int s = 0; s < NSLICE; ++s) {
+        load_tile<P, 1, HT, true>(x[s], hs, tok, n_tokens, d, s, lane);
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < P; ++i) a = fmaf(x[s][i][0], x[s][i][0], a);
+        ss[s] = a;
     }
-    float ss = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-        if (4 * (lane + 64 * j) < d) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ss = fmaf(x[j][u], x[j][u], ss);
-        }
-    const float total = wave_tree_sum(ss, lane);
+    const float total = canonical_row_total(ss, lane);
     const float ms = total / (float)d;
     const float rs = 1.0f / __builtin_sqrtf(ms + eps);
     if (lane == 0) rs_out[tok] = rs;
     float *orow = normed + (size_t)tok * d;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int e0 = 4 * (lane + 64 * j);
-        if (e0 < d) {
-            const f4 wv = *reinterpret_cast<const f4 *>(w + e0);
-            f4 o;
-            o.x = (x[j][0] * rs) * (1.0f + wv.x); o.y = (x[j][1] * rs) * (1.0f + wv.y);
-            o.z = (x[j][2] * rs) * (1.0f + wv.z); o.w = (x[j][3] * rs) * (1.0f + wv.w);
-            __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(orow + e0));
-        }
+    for (int s = 0; s < NSLICE; ++s) {
+        float w1[P][1];
+        load_tile<P, 1, float, true>(w1, w, 0, 1, d, s, lane);
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            store_run_ending_at<P>(orow, s, lane, i, [&](int k) { return (x[s][k][0] * rs) * (1.0f + w1[k][0]); });
     }
 }
 
@@ -2321,13 +2321,14 @@ int rqae_hip_gemma_norm(const void *hs, int hs_dtype, const float *norm_weight, 
     if (nblk > 0x7fffffffLL) return fail("gemma_norm: too many tokens for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t hsz = hs_dtype == RQAE_X_F32 ? 4 : 2;
-    const bool vec = d % 4 == 0 && d <= 4096 && (reinterpret_cast<uintptr_t>(hs) % (4 * hsz)) == 0 &&
-                     ((size_t)d * hsz) % (4 * hsz) == 0 && (reinterpret_cast<uintptr_t>(normed) & 15) == 0 &&
+    const int P = d / 256;
+    const bool vec = d % 256 == 0 && (P == 1 || P == 4 || P == 9 || P == 14) &&
+                     (reinterpret_cast<uintptr_t>(hs) % (4 * hsz)) == 0 && (reinterpret_cast<uintptr_t>(normed) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(norm_weight) & 15) == 0;
     if (vec) {
-#define NORM_VEC(HT, NJ) hipLaunchKernelGGL((gemma_norm_vec_kernel<HT, NJ>), dim3((unsigned)nblk), dim3(256), 0, s, \
+#define NORM_VEC(HT, PP) hipLaunchKernelGGL((gemma_norm_vec_kernel<HT, PP>), dim3((unsigned)nblk), dim3(256), 0, s, \
                                             (const HT *)hs, norm_weight, eps, (long long)n_tokens, d, normed, inv_rms)
-#define NORM_VEC_D(HT) do { if (d <= 1024) NORM_VEC(HT, 4); else if (d <= 2304) NORM_VEC(HT, 9); else NORM_VEC(HT, 16); } while (0)
+#define NORM_VEC_D(HT) do { if (P == 1) NORM_VEC(HT, 1); else if (P == 4) NORM_VEC(HT, 4); else if (P == 9) NORM_VEC(HT, 9); else NORM_VEC(HT, 14); } while (0)
         if (hs_dtype == RQAE_X_F16) NORM_VEC_D(_Float16);
         else if (hs_dtype == RQAE_X_BF16) NORM_VEC_D(uint16_t);
         else NORM_VEC_D(float);

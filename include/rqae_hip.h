@@ -106,6 +106,17 @@ int rqae_hip_decode_values(const void *packed, int d, int c, int K, int L, const
  *                         back into hs_inout in its own dtype (rqae/model.py:289) and, if new_out != NULL,
  *                         also as fp32 [n][d] (what the reference hands to store("new", ...)).
  */
+/*
+ * rqae_hip_encode_gemma: rqae_hip_gemma_norm folded into rqae_hip_encode -- the hooked layer's output goes in, the
+ * RMSNorm is applied while the tile sits in registers (same arithmetic and order as rqae_hip_gemma_norm, so the
+ * codes and q_out are bit-equal to the two-call form), normed is never written.  inv_rms [n_tokens] comes out for
+ * rqae_hip_gemma_denorm_patch.  Only for shapes served by the LDS kernel: rqae_hip_encode_gemma_supported
+ * returns 1 for them, 0 otherwise (then call rqae_hip_gemma_norm + rqae_hip_encode).
+ */
+int rqae_hip_encode_gemma_supported(int d, int c, int K, int L);
+int rqae_hip_encode_gemma(const void *packed, int d, int c, int K, int L, const void *hs, int hs_dtype,
+                          const float *norm_weight, float eps, int64_t n_tokens, int levels, float *q_out,
+                          int64_t *indices, float *inv_rms, void *stream);
 int rqae_hip_gemma_norm(const void *hs, int hs_dtype, const float *norm_weight, float eps, int64_t n_tokens,
                         int d, float *normed, float *inv_rms, void *stream);
 int rqae_hip_gemma_denorm_patch(const float *q_out, const float *norm_weight, const float *inv_rms,

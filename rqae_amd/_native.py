@@ -28,6 +28,8 @@ SYMBOLS = (
     "rqae_hip_quantize",
     "rqae_hip_decode",
     "rqae_hip_decode_values",
+    "rqae_hip_encode_gemma_supported",
+    "rqae_hip_encode_gemma",
     "rqae_hip_gemma_norm",
     "rqae_hip_gemma_denorm_patch",
     "rqae_hip_intensity_prepare",
@@ -68,6 +70,10 @@ def lib():
     L.rqae_hip_decode.restype = i
     L.rqae_hip_decode_values.argtypes = [vp, i, i, i, i, vp, i64, i, vp, vp, vp]
     L.rqae_hip_decode_values.restype = i
+    L.rqae_hip_encode_gemma_supported.argtypes = [i, i, i, i]
+    L.rqae_hip_encode_gemma_supported.restype = i
+    L.rqae_hip_encode_gemma.argtypes = [vp, i, i, i, i, vp, i, vp, ctypes.c_float, i64, i, vp, vp, vp, vp]
+    L.rqae_hip_encode_gemma.restype = i
     L.rqae_hip_gemma_norm.argtypes = [vp, i, vp, ctypes.c_float, i64, i, vp, vp, vp]
     L.rqae_hip_gemma_norm.restype = i
     L.rqae_hip_gemma_denorm_patch.argtypes = [vp, vp, vp, i64, i, i, i, vp, i, vp, vp]
@@ -209,6 +215,32 @@ def decode_values(packed, dims, cv3d: torch.Tensor, level_mask=None) -> torch.Te
                                           out.data_ptr(), _stream(cv3d.device))
     _check(rc, "rqae_hip_decode_values")
     return out
+
+
+def encode_gemma_supported(dims) -> bool:
+    d, c, K, L_ = dims
+    return bool(lib().rqae_hip_encode_gemma_supported(d, c, K, L_))
+
+
+def encode_gemma(packed, dims, hs: torch.Tensor, norm_weight: torch.Tensor, eps: float, levels: int):
+    """hs [B,S,d] {f16,bf16,f32} (the hooked layer's output) -> (q_out [B,S,d] f32, indices [B,S,levels] i64,
+    inv_rms [B,S] f32): Gemma RMSNorm + RQAE.forward in one launch (rqae/model.py:279-281)."""
+    _require_cuda(hs, "hidden states")
+    if hs.dtype not in _X_DTYPES or not hs.is_contiguous() or hs.dim() != 3:
+        raise RuntimeError("encode_gemma: hidden states must be contiguous [B,S,d] f16/bf16/f32")
+    d, c, K, L_ = dims
+    B, S, _ = hs.shape
+    w = norm_weight.detach().float().contiguous()
+    q = torch.empty((B, S, d), dtype=torch.float32, device=hs.device)
+    idx = torch.empty((B, S, levels), dtype=torch.int64, device=hs.device)
+    rs = torch.empty((B, S), dtype=torch.float32, device=hs.device)
+    if B * S:
+        with torch.cuda.device(hs.device):
+            rc = lib().rqae_hip_encode_gemma(packed.data_ptr(), d, c, K, L_, hs.data_ptr(), _X_DTYPES[hs.dtype],
+                                             w.data_ptr(), float(eps), B * S, levels, q.data_ptr(), idx.data_ptr(),
+                                             rs.data_ptr(), _stream(hs.device))
+        _check(rc, "rqae_hip_encode_gemma")
+    return q, idx, rs
 
 
 def gemma_norm(hs: torch.Tensor, norm_weight: torch.Tensor, eps: float):

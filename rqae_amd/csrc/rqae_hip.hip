@@ -410,6 +410,9 @@ struct EncParams {
     int tl_lds_floats;  // RQAE_TIMELINE builds: float offset of the stamp buffer in LDS
     const float *cb_img;  // level-0 codebook in LDS layout (make_layout), cb_img_pieces KiB
     int cb_img_pieces;
+    const float *norm_w;  // NORM kernels: Gemma RMSNorm weight [d], eps, and where 1/rms per token goes
+    float *inv_rms;
+    float norm_eps;
 };
 
 // P  : elements per lane per slice (dp = 256*P)      C : codebook_dim
@@ -832,7 +835,9 @@ __device__ __forceinline__ void pk_add_bcast(f2 &y, const f4 &quad, int c)
     else asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[1,0]" : "+v"(y) : "v"(pair));
 }
 
-template <int P, int C, bool RECON, bool MFMA>
+// NORM: x is the hooked LLM layer's output; the Gemma RMSNorm of RQAE.hook (rqae/model.py:279, rqae/llm.py:65-66)
+// is applied while the tile is in registers (rqae_hip_encode_gemma), normed never exists in HBM.
+template <int P, int C, bool RECON, bool MFMA, bool NORM = false>
 __global__ void __launch_bounds__(512, 2)
 rqae_encode_lds_kernel(const EncParams p)
 {
@@ -922,6 +927,42 @@ rqae_encode_lds_kernel(const EncParams p)
             if (p.x_dtype == RQAE_X_BF16) load_tile<P, TPW, uint16_t, false>(xt, (const uint16_t *)p.x, tokw, p.n_tokens, p.d, slice, lane);
             else if (p.x_dtype == RQAE_X_F32) load_tile<P, TPW, float, false>(xt, (const float *)p.x, tokw, p.n_tokens, p.d, slice, lane);
             else load_tile<P, TPW, _Float16, false>(xt, (const _Float16 *)p.x, tokw, p.n_tokens, p.d, slice, lane);
+        }
+        if constexpr (NORM) {
+            // normed = (x * rsqrt(mean(x^2) + eps)) * (1 + w); the row sum of squares in the canonical order of
+            // section 3 (this wave's quarter: chain over the element steps, 64-lane tree; slices through LDS)
+            float ssv[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                float a = 0.0f;
+#pragma unroll
+                for (int i = 0; i < P; ++i) a = fmaf(xt[i][t], xt[i][t], a);
+                ssv[t] = a;
+            }
+            float fin[1];
+            ReduceScatter<TPW, 0, 1>::run(ssv, fin, lane);     // lane holds token (bit5 + 2 bit4 + 4 bit3)
+            if ((lane & 7) == 0) {
+                const int t = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);
+                part[(half * TPW + t) * NSLICE + slice] = fin[0];
+            }
+            float w1[P][1];                                     // 1 + norm weight of this lane's elements
+            if (full_tile) load_tile<P, 1, float, true>(w1, p.norm_w, 0, 1, p.d, slice, lane);
+            else load_tile<P, 1, float, false>(w1, p.norm_w, 0, 1, p.d, slice, lane);
+            __syncthreads();
+            float rs_mine = 0.0f;
+            if (lane < TPW) {
+                const f4 ps = *reinterpret_cast<const f4 *>(part + (half * TPW + lane) * NSLICE);
+                const float total = (ps.x + ps.y) + (ps.z + ps.w);
+                const float ms = total / (float)p.d;
+                rs_mine = 1.0f / __builtin_sqrtf(ms + p.norm_eps);
+                if (slice == 0 && tokw + lane < p.n_tokens) p.inv_rms[tokw + lane] = rs_mine;
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const float rs = lane_bcast(rs_mine, t);
+#pragma unroll
+                for (int i = 0; i < P; ++i) xt[i][t] = (xt[i][t] * rs) * (1.0f + w1[i][0]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < P; ++i)
@@ -1315,6 +1356,10 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
         HIP_TRY(hipGetLastError());
         return 0;
     };
+    if (p.norm_w) {
+        if (!p.q_out) return fail("encode_gemma: the reconstruction output is required");
+        return go(rqae_encode_lds_kernel<P, C, true, false, true>);
+    }
     if (use_mfma) {
         if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, true>);
         return go(rqae_encode_lds_kernel<P, C, false, true>);
@@ -2244,6 +2289,44 @@ int rqae_hip_encode(const void *packed, int d, int c, int K, int L, const void *
     p.x = x; p.q_out = q_out; p.idx = reinterpret_cast<long long *>(indices);
     p.n_tokens = n_tokens; p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.levels = levels; p.x_dtype = x_dtype;
     p.aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q_out)) & 15) == 0;
+    int rc = 0;
+    dispatch_encode(v.dp / 256, c, &p, static_cast<hipStream_t>(stream), &rc);
+    return rc;
+}
+
+// shapes whose encode kernel can apply the Gemma norm on load (the LDS kernel's instantiations)
+static bool gemma_fusable(int d, int c)
+{
+    const int P = (d + 255) / 256;
+    return env_variant() == V_AUTO && d % 256 == 0 && ((P == 9 && (c == 5 || c == 4)) || (P == 1 && c == 4));
+}
+
+int rqae_hip_encode_gemma_supported(int d, int c, int K, int L)
+{
+    return shape_ok(d, c, K, L) && gemma_fusable(d, c) ? 1 : 0;
+}
+
+int rqae_hip_encode_gemma(const void *packed, int d, int c, int K, int L, const void *hs, int hs_dtype,
+                          const float *norm_weight, float eps, int64_t n_tokens, int levels, float *q_out,
+                          int64_t *indices, float *inv_rms, void *stream)
+{
+    if (!shape_ok(d, c, K, L)) return fail("encode_gemma: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    if (!gemma_fusable(d, c)) return fail("encode_gemma: no fused kernel for d=%d c=%d (see rqae_hip_encode_gemma_supported)", d, c);
+    if (!packed || !hs || !indices || !norm_weight || !inv_rms || !q_out) return fail("encode_gemma: null pointer");
+    if (levels < 1 || levels > L) return fail("encode_gemma: levels=%d outside 1..%d", levels, L);
+    if (hs_dtype < RQAE_X_F32 || hs_dtype > RQAE_X_F16) return fail("encode_gemma: bad hs_dtype %d", hs_dtype);
+    if (n_tokens < 0) return fail("encode_gemma: negative n_tokens");
+    if (n_tokens == 0) return 0;
+    const PackedView v = view_of(packed, d, c, K, L);
+    EncParams p;
+    memset(&p, 0, sizeof(p));
+    p.w_in = v.w_in; p.w_out = v.w_out; p.b_out = v.b_out; p.b_in = v.b_in; p.cb = v.cb; p.hdr = v.hdr;
+    p.rec_p = v.rec_p; p.cb_img = v.cb_img; p.cb_img_pieces = v.cb_img_pieces;
+    p.x = hs; p.q_out = q_out; p.idx = reinterpret_cast<long long *>(indices);
+    p.n_tokens = n_tokens; p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.levels = levels; p.x_dtype = hs_dtype;
+    p.norm_w = norm_weight; p.inv_rms = inv_rms; p.norm_eps = eps;
+    p.aligned16 = ((reinterpret_cast<uintptr_t>(hs) | reinterpret_cast<uintptr_t>(q_out) |
+                    reinterpret_cast<uintptr_t>(norm_weight)) & 15) == 0;
     int rc = 0;
     dispatch_encode(v.dp / 256, c, &p, static_cast<hipStream_t>(stream), &rc);
     return rc;

@@ -401,9 +401,10 @@ class RQAE(nn.Module):
 
     def _gemma_hook(self, final_norm, generic_hook, **kwargs):
         """hook() for an LLM whose norm/denorm are Gemma-2's (rqae/llm.py:65-73): the RMSNorm before
-        forward and the denorm + BOS skip + in-place write-back after it run as two HIP kernels
-        (include/rqae_hip.h: rqae_hip_gemma_norm / rqae_hip_gemma_denorm_patch) instead of ~12 torch
-        ops and their fp32 temporaries.  Same store() protocol and side effects as the generic hook."""
+        forward runs inside the encode kernel (rqae_hip_encode_gemma; as its own kernel when a store
+        wants `normed`), the denorm + BOS skip + in-place write-back after it as one HIP kernel
+        (rqae_hip_gemma_denorm_patch) -- instead of ~12 torch ops and their fp32 temporaries.  Same
+        store() protocol and side effects as the generic hook."""
         store = kwargs.get("store", None)
         skip_bos = kwargs.get("skip_bos", True)
         replace = kwargs.get("replace", True)
@@ -416,10 +417,18 @@ class RQAE(nn.Module):
                 return generic_hook(module, input, output)   # same values, torch ops around forward()
             if store is not None:
                 store("original", hs_llm.float())
-            normed, inv_rms = _native.gemma_norm(hs_llm, final_norm.weight, eps)
-            if store is not None:
-                store("normed", normed.detach().clone())
-            q_out, codes = self(normed)
+            fold = (store is None and hs_llm.shape[-1] == self._dim and self.quantization_method in _FSQ_METHODS
+                    and _native.encode_gemma_supported(self._dims()))
+            if fold:
+                # nobody asked for `normed`: the norm runs inside the encode kernel's load (same bits)
+                q_out, codes, inv_rms = _native.encode_gemma(self.packed_weights(), self._dims(), hs_llm,
+                                                             final_norm.weight, eps, self.num_quantizers)
+                self.update_codebook_counts(codes)
+            else:
+                normed, inv_rms = _native.gemma_norm(hs_llm, final_norm.weight, eps)
+                if store is not None:
+                    store("normed", normed.detach().clone())
+                q_out, codes = self(normed)
             if store is not None:
                 store("quantized", q_out.detach().clone())
                 store("indices", codes.detach().clone())

@@ -553,3 +553,31 @@ def test_forward_and_decode_capture_into_a_hip_graph():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(idx, idx_ref) and torch.equal(q, q_ref) and torch.equal(d, d_ref)
+
+
+@pytest.mark.parametrize("cfgname,dtype,n", [("C2", torch.float16, 1000), ("C2", torch.bfloat16, 37),
+                                             ("C1", torch.float32, 4096), ("P", torch.float16, 130)])
+def test_encode_gemma_folds_the_norm(cfgname, dtype, n):
+    """rqae_hip_encode_gemma (RMSNorm applied in the encode kernel's load) == rqae_hip_gemma_norm followed by
+    rqae_hip_encode, bit for bit, and == the oracle; ragged tiles and all hs dtypes."""
+    cfg = dict(synth.CONFIGS[cfgname])
+    if cfgname == "P":
+        cfg["num_quantizers"] = 6
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    d = cfg["dim"]
+    rng = np.random.Generator(np.random.PCG64(n))
+    nw = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    hs = (torch.from_numpy(synth.activations(3, n, d)) * 3.0).to(dtype).to(DEV).view(1, n, d)
+    wt = torch.from_numpy(nw).to(DEV)
+    assert _native.encode_gemma_supported(m._dims())
+    with torch.inference_mode():
+        q, idx, rs = _native.encode_gemma(m.packed_weights(), m._dims(), hs, wt, 1e-6, cfg["num_quantizers"])
+        normed, rs2 = _native.gemma_norm(hs, wt, 1e-6)
+        q2, idx2 = m(normed)
+    torch.cuda.synchronize()
+    assert torch.equal(rs, rs2) and torch.equal(idx, idx2) and torch.equal(q, q2)
+    normed_o, rs_o = oracle.gemma_norm_canonical(hs.float().cpu().numpy()[0], nw)
+    assert np.array_equal(rs.cpu().numpy()[0], rs_o) and np.array_equal(normed.cpu().numpy()[0], normed_o)
+    q_o, idx_o = oracle.forward(normed_o, w)
+    assert np.array_equal(idx.cpu().numpy()[0], idx_o) and np.array_equal(q.cpu().numpy()[0], q_o)

@@ -50,7 +50,19 @@ constexpr int MAX_C = 16;
 constexpr int MAX_MASK_LEVELS = 2048;
 constexpr size_t LDS_CODEBOOK_BUDGET = 96 * 1024;
 
-thread_local char g_err[512] = "";
+}  // namespace
+// Two translation units are built from this file (__graft_entry__.py): the main path's kernels -- the LDS
+// encode kernel for d = 2304, packed-VALU arm -- with the ILP-first machine scheduler
+// (-mllvm -amdgpu-sched-strategy=max-ilp, -DRQAE_TU_MAIN: +2-4 % on them, but it slows the small shapes and makes
+// the generic kernels spill), everything else with the default one.  They share the error text and one launcher.
+#ifdef RQAE_TU_MAIN
+extern __attribute__((visibility("hidden"))) thread_local char rqae_g_err[512];
+#else
+__attribute__((visibility("hidden"))) thread_local char rqae_g_err[512] = "";
+#endif
+extern "C" __attribute__((visibility("hidden"))) int rqae_main_tu_launch(int c, const void *enc_params, void *stream);
+namespace {
+#define g_err rqae_g_err
 
 int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 int fail(const char *fmt, ...)
@@ -415,6 +427,7 @@ struct EncParams {
     float norm_eps;
 };
 
+#ifndef RQAE_TU_MAIN   // (the main path's translation unit carries only rqae_encode_lds_kernel, see the end of this section)
 // P  : elements per lane per slice (dp = 256*P)      C : codebook_dim
 // TPW: tokens held by one wave                        NH: token halves (waves = 4*NH)
 // GEN: P and C are upper bounds, the live sizes come from EncParams (slow generic path)
@@ -592,6 +605,7 @@ rqae_encode_kernel(const EncParams p)
             }
     }
 }
+#endif  // !RQAE_TU_MAIN
 
 
 
@@ -1356,18 +1370,51 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
         HIP_TRY(hipGetLastError());
         return 0;
     };
+#if !defined(RQAE_TU_MAIN) && !defined(RQAE_SINGLE_TU)
+    if constexpr (P == 9) {
+        if (!use_mfma) return rqae_main_tu_launch(C, &p, stream);   // compiled in the other translation unit
+    }
+#endif
     if (p.norm_w) {
         if (!p.q_out) return fail("encode_gemma: the reconstruction output is required");
+        if (use_mfma) return fail("encode_gemma: no MFMA arm");
+#if defined(RQAE_TU_MAIN) || defined(RQAE_SINGLE_TU)
         return go(rqae_encode_lds_kernel<P, C, true, false, true>);
+#else
+        if constexpr (P != 9) return go(rqae_encode_lds_kernel<P, C, true, false, true>);
+#endif
     }
+#ifndef RQAE_TU_MAIN
     if (use_mfma) {
         if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, true>);
         return go(rqae_encode_lds_kernel<P, C, false, true>);
     }
+#endif
+#if defined(RQAE_TU_MAIN) || defined(RQAE_SINGLE_TU)
     if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, false>);
     return go(rqae_encode_lds_kernel<P, C, false, false>);
+#else
+    if constexpr (P != 9) {
+        if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, false>);
+        return go(rqae_encode_lds_kernel<P, C, false, false>);
+    }
+    return fail("encode: unreachable");
+#endif
 }
 
+#ifdef RQAE_TU_MAIN
+}  // namespace
+extern "C" __attribute__((visibility("hidden"))) int rqae_main_tu_launch(int c, const void *enc_params, void *stream)
+{
+    const EncParams &p = *static_cast<const EncParams *>(enc_params);
+    if (c == 5) return launch_encode_lds<9, 5>(p, static_cast<hipStream_t>(stream), false);
+    if (c == 4) return launch_encode_lds<9, 4>(p, static_cast<hipStream_t>(stream), false);
+    return fail("encode: no main-path kernel for c=%d", c);
+}
+namespace {
+#endif
+
+#ifndef RQAE_TU_MAIN
 template <int P, int C, int TPW, int NH, bool GEN>
 int launch_encode(const EncParams &p, hipStream_t stream)
 {
@@ -1843,13 +1890,6 @@ int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t
 // One wave per token.  Order of the mean: lane owns elements 4*(lane + 64*j) + {0..3}, j ascending,
 // fma chain of squares from +0 per lane, lanes summed by the tree of section 3, divided by d;
 // rs = 1 / sqrt(ms + eps) with IEEE sqrt and divide (oracle/oracle.py:gemma_norm_canonical restates it).
-__device__ __forceinline__ float wave_tree_sum(float v, int lane)
-{
-    float a[1] = {v}, fin[1];
-    ReduceScatter<1, 0, 1>::run(a, fin, lane);   // all singles: every lane ends with the full tree sum
-    return fin[0];
-}
-
 // Sum of the four slice totals of every lane's value (in: per-lane partial of slice s in ss[s]) in the order of
 // section 3: the 64-lane tree per slice, then (s0+s1)+(s2+s3).  Every lane returns the row total.
 __device__ __forceinline__ float canonical_row_total(const float (&ss)[NSLICE], int lane)
@@ -2518,3 +2558,6 @@ int rqae_hip_intensity(const void *table, const void *layer_weights, const void 
 }
 
 }  // extern "C"
+#else   // RQAE_TU_MAIN
+}  // namespace
+#endif  // !RQAE_TU_MAIN

@@ -13,11 +13,12 @@ import rqae_amd._native as nat
 import subprocess
 TL_SO = os.path.join(ROOT, "tools", "_build", "librqae_hip_tl.so")
 SRC = os.path.join(ROOT, "rqae_amd", "csrc", "rqae_hip.hip")
-if not os.path.exists(TL_SO) or os.path.getmtime(TL_SO) < os.path.getmtime(SRC):
+if not os.path.exists(TL_SO) or any(os.path.getmtime(TL_SO) < os.path.getmtime(os.path.join(os.path.dirname(SRC), f))
+                                    for f in ("rqae_hip.hip", "encode_lds.hpp", "rqae_common.hpp")):
     os.makedirs(os.path.dirname(TL_SO), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
                     "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-                    "-DRQAE_SINGLE_TU", "-DRQAE_TIMELINE", "-DRQAE_EXPERIMENT_ONLY_95", SRC, "-o", TL_SO],
+                    "-DRQAE_SINGLE_TU", "-DRQAE_TIMELINE", "-DRQAE_EXPERIMENT_ONLY_95", SRC, "-o", TL_SO],     # one translation unit
                    check=True, cwd=os.path.dirname(SRC))
 nat.SO_PATH = TL_SO
 from rqae_amd import RQAE, synth

@@ -27,9 +27,10 @@
 // residual never goes back to HBM); weights stream from L2 once per level per
 // workgroup (LDS-DMA into LDS in rqae_encode_lds_kernel, the main path); the only
 // exchange per level is 4c partial sums in and c floats out per token through LDS.
-// Kernels, in file order: pack; rqae_encode_kernel (generic shapes); rqae_encode_lds_kernel
-// (main); rqae_quantize_kernel; rqae_decode_kernel / rqae_decode_lds_kernel; the hook
-// kernels; intensity.  DESIGN.md section 5 describes each with its roofline.
+// Files: encode_lds.hpp (rqae_encode_lds_kernel, the main path; its d = 2304 instantiations are the
+// translation unit encode_main.hip), this file (pack, rqae_encode_kernel for generic shapes, dispatch,
+// C ABI), decode.hpp (quantize + decode kernels), hook.hpp, intensity.hpp, rqae_common.hpp (shared
+// helpers).  DESIGN.md section 5 describes each kernel with its roofline.
 #include "encode_lds.hpp"
 
 namespace {
@@ -367,713 +368,13 @@ const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream
 #endif
 }
 
-// ---------------------------------------------------------------- quantize kernel
-struct QuantParams {
-    const float *p, *cb;
-    float *cv;
-    long long *idx;
-    long long n;
-    int c, K, kch, iters;
-};
+}  // namespace
 
-// One workgroup = 4 waves; a wave quantises TQ tokens at a time.  When the codebook fits in LDS in one chunk it is
-// staged once per workgroup and the waves walk `iters` token groups against it (staging 20 KB per 16 tokens was
-// 25x the algorithmic bytes); a chunked codebook keeps one group per workgroup (the running maxima of a group
-// live in registers across the chunks).
-template <int C>
-__global__ void __launch_bounds__(256)
-rqae_quantize_kernel(const QuantParams p)
-{
-    constexpr int TQ = 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cp = p.c;
-    const int nchunk = (p.K + p.kch - 1) / p.kch;
-    if (nchunk == 1) {
-        stage_floats(smem, p.cb, p.K * cp);
-        __syncthreads();
-    }
-    for (int it = 0; it < p.iters; ++it) {
-        const long long tokw = (((long long)blockIdx.x * p.iters + it) * 4 + wave) * TQ;
-        if (nchunk == 1 && tokw >= p.n) break;                // wave-uniform; (a chunked codebook has barriers below: every wave stays)
-        float q[TQ][C], xn[TQ][C], best[TQ];
-        int bidx[TQ];
-#pragma unroll
-        for (int tq = 0; tq < TQ; ++tq) {
-            const long long tok = tokw + tq;
-#pragma unroll
-            for (int j = 0; j < C; ++j) q[tq][j] = (j < cp && tok < p.n) ? p.p[tok * cp + j] : 0.0f;
-            const float nrm = aten_norm2<C>(q[tq], cp);
-#pragma unroll
-            for (int j = 0; j < C; ++j) xn[tq][j] = q[tq][j] / nrm;
-            best[tq] = -INFINITY;
-            bidx[tq] = 0;
-        }
-        if (nchunk == 1) {
-            scan_rows<C, TQ>(xn, smem, p.K, 0, cp, lane, best, bidx);
-        } else {
-            for (int ch = 0; ch < nchunk; ++ch) {             // iters == 1 here: every wave of the block takes part
-                const int row_base = ch * p.kch;
-                const int rows = (p.K - row_base) < p.kch ? (p.K - row_base) : p.kch;
-                if (ch > 0) __syncthreads();
-                stage_floats(smem, p.cb + (size_t)row_base * cp, rows * cp);
-                __syncthreads();
-                scan_rows<C, TQ>(xn, smem, rows, row_base, cp, lane, best, bidx);
-            }
-        }
-#pragma unroll
-        for (int tq = 0; tq < TQ; ++tq) {
-            wave_argmax(best[tq], bidx[tq]);
-            const long long tok = tokw + tq;
-            if (tok < p.n) {
-                if (lane == 0) p.idx[tok] = bidx[tq];
-                if (lane < cp) p.cv[tok * cp + lane] = p.cb[(size_t)bidx[tq] * cp + lane];
-            }
-        }
-    }
-}
+#include "decode.hpp"
+#include "hook.hpp"
+#include "intensity.hpp"
 
-// ------------------------------------------------------------------ decode kernel
-struct DecParams {
-    const float *w_out, *b_out, *cb0;
-    const void *src;  // indices [n][nq] or cv [n][nq][c]
-    float *out;
-    long long n_tokens;
-    int d, dp, c, K, nlev, nq, idx_dtype;
-    const float *rec_p;   // pass records (rqae_decode_lds_kernel reads the lin_out quads of record l+1)
-    int aligned16;        // out 16-byte aligned: full tiles use vector stores
-    uint32_t mask[MAX_MASK_LEVELS / 32];
-};
-
-__device__ __forceinline__ long long load_idx(const void *src, int dt, size_t off)
-{
-    if (dt == RQAE_IDX_I64) return reinterpret_cast<const long long *>(src)[off];
-    if (dt == RQAE_IDX_I32) return reinterpret_cast<const int *>(src)[off];
-    return reinterpret_cast<const uint16_t *>(src)[off];
-}
-
-// One workgroup = 4 waves (one per slice) x TPW tokens; the running sum stays in VGPRs,
-// lin_out weights stream once per workgroup.  LCH levels of codebook values are staged in LDS.
-template <int P, int C, int TPW, bool FROM_IDX, bool GEN>
-__global__ void __launch_bounds__(256)
-rqae_decode_kernel(const DecParams p)
-{
-    constexpr int LCH = 16;
-    __shared__ float cvl[TPW * LCH * C];
-    const int lane = threadIdx.x & 63;
-    const int slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cp = GEN ? p.c : C;
-    const int Pp = GEN ? p.dp / 256 : P;
-    const int dp = GEN ? p.dp : 256 * P;
-    auto el = [&](int i) { return elem_of(Pp, slice, i, lane); };
-    const long long tok0 = (long long)blockIdx.x * TPW;
-
-    float acc[P][TPW];
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[i][t] = 0.0f;
-    bool first = true;
-
-    for (int l0 = 0; l0 < p.nlev; l0 += LCH) {
-        const int lch = (p.nlev - l0) < LCH ? (p.nlev - l0) : LCH;
-        __syncthreads();
-        for (int u = threadIdx.x; u < TPW * lch; u += blockDim.x) {
-            const int t = u / lch, ll = u % lch, l = l0 + ll;
-            const long long tok = tok0 + t;
-            const bool on = (p.mask[l >> 5] >> (l & 31)) & 1u;
-            if (!on || tok >= p.n_tokens) continue;
-            const float *row;
-            if constexpr (FROM_IDX) {
-                const long long ix = load_idx(p.src, p.idx_dtype, (size_t)tok * p.nq + l);
-                row = p.cb0 + (size_t)ix * cp;  // level-0 codebook for every level (model.py:234)
-            } else {
-                row = reinterpret_cast<const float *>(p.src) + ((size_t)tok * p.nq + l) * cp;
-            }
-            for (int k = 0; k < cp; ++k) cvl[(t * LCH + ll) * C + k] = row[k];
-        }
-        __syncthreads();
-        for (int ll = 0; ll < lch; ++ll) {
-            const int l = l0 + ll;
-            if (!((p.mask[l >> 5] >> (l & 31)) & 1u)) continue;
-            const float *wl = p.w_out + (size_t)l * cp * dp;
-            const float *bl = p.b_out + (size_t)l * dp;
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                if (GEN && i >= Pp) continue;
-                float w[C];
-#pragma unroll
-                for (int k = 0; k < C; ++k) w[k] = (!GEN || k < cp) ? wl[(size_t)k * dp + el(i)] : 0.0f;
-                const float b = bl[el(i)];
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    float y = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < C; ++k)
-                        if (!GEN || k < cp) y = fmaf(cvl[(t * LCH + ll) * C + k], w[k], y);
-                    y = y + b;
-                    acc[i][t] = first ? y : acc[i][t] + y;  // first level assigns (model.py:244-247)
-                }
-            }
-            first = false;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const int e = el(i);
-            const long long tok = tok0 + t;
-            if ((!GEN || i < Pp) && e < p.d && tok < p.n_tokens) p.out[(size_t)tok * p.d + e] = acc[i][t];
-        }
-}
-
-template <int P, int C, int TPW, bool GEN>
-int launch_decode(const DecParams &p, bool from_idx, hipStream_t stream)
-{
-    const long long nblk = (p.n_tokens + TPW - 1) / TPW;
-    if (nblk > 0x7fffffffLL) return fail("decode: too many tokens for one launch");
-    if (from_idx)
-        hipLaunchKernelGGL((rqae_decode_kernel<P, C, TPW, true, GEN>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((rqae_decode_kernel<P, C, TPW, false, GEN>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-
-// =============================================================== LDS-staged decode kernel
-// Decode has no dependency between levels and no cross-lane reduction: out = sum_l (lin_out_l(cv_l)),
-// ascending, first selected level assigns (rqae/model.py:236-248).  Same geometry as the encode
-// kernel (8 waves = 4 slices x 2 token halves, 8 tokens per wave, packed fp32 over token pairs); the
-// lin_out weights of a level are the first two quads of every element step of pass record l+1
-// (w_out[0..c-1], b_out), copied L2 -> LDS by LDS-DMA into one of TWO buffers, so level l+1 loads while
-// level l computes.  Codebook values of the tile (16 tokens x 32 levels x c) are gathered into LDS.
-// NBUF = 2: the next level's weights load into a second LDS buffer behind the current level (one workgroup per CU).
-// NBUF = 1: one buffer, 66 KB of LDS and <= 128 VGPRs, so TWO workgroups share a CU and cover each other's load and
-//           barrier waits (the kernel is VALU-bound once those are hidden).
-template <int P, int C, bool FROM_IDX, int NBUF>
-__global__ void __launch_bounds__(512, NBUF == 1 ? 4 : 2)
-rqae_decode_lds_kernel(const DecParams p)
-{
-    constexpr int TPW = 8, NW = 8, TG = 16, NPAIR = 4, NG = 2, LCH = 32;
-    constexpr int NQ = rec_quads(P, C);          // quads per lane per slice in a pass record
-    constexpr int QD = rec_out_quads(P, C);      // its leading quads: the packed {w_out[0..C-1], b_out} stream
-    constexpr int W = C + 1;
-    constexpr int BUF = NSLICE * QD * 256;       // floats per weight buffer
-    constexpr int dp = 256 * P;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wbuf = smem;                          // [NBUF][slice][QD][lane][4]
-    float *cvl = wbuf + NBUF * BUF;                 // [LCH][C][TG]  (token pairs contiguous)
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slice = wave & 3, half = wave >> 2;
-    const long long tok0 = (long long)blockIdx.x * TG;
-    const long long tokw = tok0 + half * TPW;
-    const bool full_tile = (tokw + TPW <= p.n_tokens) && (p.d == dp) && p.aligned16;
-    const unsigned wbuf_addr = lds_addr_of(wbuf);
-
-    auto level_on = [&](int l) { return ((p.mask[l >> 5] >> (l & 31)) & 1u) != 0; };
-    auto next_on = [&](int l) { while (l < p.nlev && !level_on(l)) ++l; return l; };   // uniform scalar loop
-    // lin_out quads of level l (record l+1) -> buffer b; the 8 waves share the (slice, i) chunks
-    auto issue_dma = [&](int l, int b) {
-        const float *rec = p.rec_p + (size_t)(l + 1) * NSLICE * NQ * 256;
-        for (int pc = wave; pc < NSLICE * QD; pc += NW) {
-            const int s = pc / QD, q = pc - s * QD;
-            dma_pieces<1>(rec + (size_t)(s * NQ + q) * 256, wbuf_addr + (b * BUF + pc * 256) * 4, lane * 16);
-        }
-    };
-
-    f2 acc[P][NPAIR];
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-#pragma unroll
-        for (int pr = 0; pr < NPAIR; ++pr) acc[i][pr] = splat2(0.0f);
-    bool first = true;
-
-    int l = next_on(0), buf = 0;
-    if (l < p.nlev) issue_dma(l, 0);
-    int staged_from = -1;                         // first level of the codebook-value chunk in LDS
-    bool first_level = true;
-    while (l < p.nlev) {
-        const int ln = next_on(l + 1);
-        if constexpr (NBUF == 1) {
-            if (!first_level) {
-                __syncthreads();                              // every wave is done with the previous level's weights
-                issue_dma(l, 0);
-            }
-            first_level = false;
-        }
-        if (l >= staged_from + LCH || staged_from < 0) {
-            // gather this tile's codebook values for levels [l, l+LCH)
-            if (staged_from >= 0) __syncthreads();            // previous chunk no longer read
-            staged_from = l;
-            for (int u = threadIdx.x; u < TG * LCH; u += blockDim.x) {
-                const int t = u % TG, ll = u / TG, lv = l + ll;
-                const long long tok = tok0 + t;
-                if (lv >= p.nlev || !level_on(lv) || tok >= p.n_tokens) continue;
-                const float *row;
-                if constexpr (FROM_IDX) {
-                    const long long ix = load_idx(p.src, p.idx_dtype, (size_t)tok * p.nq + lv);
-                    row = p.cb0 + (size_t)ix * C;             // level-0 codebook for every level (model.py:234)
-                } else {
-                    row = reinterpret_cast<const float *>(p.src) + ((size_t)tok * p.nq + lv) * C;
-                }
-#pragma unroll
-                for (int k = 0; k < C; ++k) cvl[(ll * C + k) * TG + t] = row[k];
-            }
-        }
-        dma_wait_all();
-        __syncthreads();                                      // weights of level l + codebook values visible
-        // next selected level loads behind this one: one piece per element step (a burst of all pieces waits
-        // on the TA's address queue, see the encode kernel)
-        int dpc = (NBUF == 2 && ln < p.nlev) ? wave : NSLICE * QD;
-        const float *drec = p.rec_p + (size_t)(ln + 1) * NSLICE * NQ * 256;
-        auto dma_step = [&]() __attribute__((always_inline)) {
-            if (dpc < NSLICE * QD) {
-                const int s = dpc / QD, q = dpc - s * QD;
-                dma_pieces<1>(drec + (size_t)(s * NQ + q) * 256, wbuf_addr + ((buf ^ 1) * BUF + dpc * 256) * 4, lane * 16);
-                dpc += NW;
-            }
-        };
-
-        const f4 *wl = reinterpret_cast<const f4 *>(wbuf + buf * BUF) + (size_t)slice * QD * 64 + lane;
-        const float *cvp = cvl + (l - staged_from) * C * TG + half * TPW;
-        // element step outermost: every weight quad is read from LDS once for the wave's 8 tokens
-        f2 cv2[NG][2][C];
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const f2 v = *reinterpret_cast<const f2 *>(cvp + k * TG + 4 * g + 2 * pr);
-                    cv2[g][pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
-                }
-        asm volatile("s_nop 3" ::: "memory");   // v_readfirstlane -> SGPR read by the asm below
-        f4 wq[QD];
-#pragma unroll
-        for (int q = 0; q < QD; ++q)
-            if (q <= last_quad_of_step(0, W)) wq[q] = wl[q * 64];
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-#pragma unroll
-            for (int q = 0; q < QD; ++q)
-                if (i + 1 < P && q > last_quad_of_step(i, W) && q <= last_quad_of_step(i + 1, W)) wq[q] = wl[q * 64];
-            dma_step();
-            f2 yy[NG][2];   // the four chains interleaved, as in the encode kernel's sweep 1
-#pragma unroll
-            for (int k = 0; k < C; ++k)
-#pragma unroll
-                for (int g = 0; g < NG; ++g)
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr)
-                        pk_fma_bcast_s(yy[g][pr], cv2[g][pr][k], wq[(i * W + k) / 4], (i * W + k) % 4, k == 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    pk_add_bcast(yy[g][pr], wq[(i * W + C) / 4], (i * W + C) % 4);
-                    if (first) acc[i][2 * g + pr] = yy[g][pr];     // first selected level assigns (model.py:244-247)
-                    else acc[i][2 * g + pr] = acc[i][2 * g + pr] + yy[g][pr];
-                }
-        }
-        while (dpc < NSLICE * QD) dma_step();                 // more pieces per wave than element steps
-        first = false;
-        l = ln;
-        if constexpr (NBUF == 2) buf ^= 1;
-    }
-
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const long long tok = tokw + t;
-        float *op = p.out + (size_t)(tok < p.n_tokens ? tok : 0) * p.d;
-        auto val = [&](int k) { return (t & 1) ? acc[k][t >> 1].y : acc[k][t >> 1].x; };
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            if (full_tile) store_run_ending_at<P>(op, slice, lane, i, val);
-            else {
-                const int e = elem_of(P, slice, i, lane);
-                if (tok < p.n_tokens && e < p.d) op[e] = val(i);
-            }
-        }
-    }
-}
-
-template <int P, int C>
-int launch_decode_lds(const DecParams &p, bool from_idx, hipStream_t stream)
-{
-    constexpr int QD = rec_out_quads(P, C);
-    const char *nb = getenv("RQAE_HIP_DECODE_NBUF");     // 2 = the double-buffered form (measured slower: 1.42 vs 1.16 ms)
-    const int nbuf = nb && atoi(nb) == 2 ? 2 : 1;
-    const size_t lds = sizeof(float) * ((size_t)nbuf * NSLICE * QD * 256 + 32 * C * 16);
-    const long long nblk = (p.n_tokens + 15) / 16;
-    if (nblk > 0x7fffffffLL) return fail("decode: too many tokens for one launch");
-    auto go = [&](auto kern) -> int {
-        if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, stream, p);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    };
-    if (nbuf == 2) {
-        if (from_idx) return go(rqae_decode_lds_kernel<P, C, true, 2>);
-        return go(rqae_decode_lds_kernel<P, C, false, 2>);
-    }
-    if (from_idx) return go(rqae_decode_lds_kernel<P, C, true, 1>);
-    return go(rqae_decode_lds_kernel<P, C, false, 1>);
-}
-
-int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t stream)
-{
-#ifdef RQAE_EXPERIMENT_ONLY_95
-    return fail("experiment build");
-#else
-    if (env_variant() == V_AUTO) {
-        if (P == 9 && c == 5) return launch_decode_lds<9, 5>(p, from_idx, stream);
-        if (P == 9 && c == 4) return launch_decode_lds<9, 4>(p, from_idx, stream);
-        if (P == 1 && c == 4) return launch_decode_lds<1, 4>(p, from_idx, stream);
-    }
-    if (env_variant() != V_GEN) {
-        if (P == 9 && c == 5) return launch_decode<9, 5, 16, false>(p, from_idx, stream);
-        if (P == 9 && c == 4) return launch_decode<9, 4, 16, false>(p, from_idx, stream);
-        if (P == 1 && c == 4) return launch_decode<1, 4, 16, false>(p, from_idx, stream);
-        if (P == 14 && c == 13) return launch_decode<14, 13, 4, false>(p, from_idx, stream);
-    }
-    if (P <= 8) return launch_decode<8, 16, 4, true>(p, from_idx, stream);
-    return launch_decode<32, 16, 4, true>(p, from_idx, stream);
-#endif
-}
-
-
-// =============================================================== hook pre/post
-// The step either side of forward() in RQAE.hook (rqae/model.py:276-289) for a Gemma-2 LLM
-// (rqae/llm.py:65-73):  normed = (hs * rsqrt(mean(hs^2) + eps)) * (1 + w)   and afterwards
-// new = (q / (1 + w)) / rsqrt(mean(hs^2) + eps), new[:, 0] = hs[:, 0], written back in the LLM's dtype.
-// One wave per token.  Order of the mean: lane owns elements 4*(lane + 64*j) + {0..3}, j ascending,
-// fma chain of squares from +0 per lane, lanes summed by the tree of section 3, divided by d;
-// rs = 1 / sqrt(ms + eps) with IEEE sqrt and divide (oracle/oracle.py:gemma_norm_canonical restates it).
-// Sum of the four slice totals of every lane's value (in: per-lane partial of slice s in ss[s]) in the order of
-// section 3: the 64-lane tree per slice, then (s0+s1)+(s2+s3).  Every lane returns the row total.
-__device__ __forceinline__ float canonical_row_total(const float (&ss)[NSLICE], int lane)
-{
-    float fin[1];
-    ReduceScatter<NSLICE, 0, 1>::run(ss, fin, lane);      // lane holds the tree sum of slice (bit5 + 2*bit4)
-    const float s0 = lane_bcast(fin[0], 0), s1 = lane_bcast(fin[0], 32);
-    const float s2 = lane_bcast(fin[0], 16), s3 = lane_bcast(fin[0], 48);
-    return (s0 + s1) + (s2 + s3);
-}
-
-// One wave per token, any d (runtime P = ceil(d / 256)), scalar loads.
-template <typename HT>
-__global__ void __launch_bounds__(256)
-gemma_norm_kernel(const HT *hs, const float *w, float eps, long long n_tokens, int d, float *normed, float *rs_out)
-{
-    const int lane = threadIdx.x & 63;
-    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= n_tokens) return;
-    const int P = (d + 255) / 256;
-    const HT *row = hs + (size_t)tok * d;
-    float ss[NSLICE];
-#pragma unroll
-    for (int s = 0; s < NSLICE; ++s) {
-        float a = 0.0f;
-        for (int i = 0; i < P; ++i) {
-            const int e = elem_of(P, s, i, lane);
-            const float x = e < d ? widen<HT>(row[e]) : 0.0f;
-            a = fmaf(x, x, a);
-        }
-        ss[s] = a;
-    }
-    const float total = canonical_row_total(ss, lane);
-    const float ms = total / (float)d;
-    const float rs = 1.0f / __builtin_sqrtf(ms + eps);
-    if (lane == 0) rs_out[tok] = rs;
-    float *orow = normed + (size_t)tok * d;
-    for (int e = lane; e < d; e += 64) {
-        const float t = widen<HT>(row[e]) * rs;
-        orow[e] = t * (1.0f + w[e]);
-    }
-}
-
-// Vector form for d == 256 * P with 16-byte aligned rows: hs is read ONCE with the tile loads of the encode
-// kernel (runs of 4 / 2 / 1 consecutive elements per lane), kept in registers across the reduction, and normed
-// is written with the matching vector stores.  Same arithmetic and order as gemma_norm_kernel.
-template <typename HT, int P>
-__global__ void __launch_bounds__(256)
-gemma_norm_vec_kernel(const HT *hs, const float *w, float eps, long long n_tokens, int d, float *normed, float *rs_out)
-{
-    const int lane = threadIdx.x & 63;
-    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= n_tokens) return;
-    float x[NSLICE][P][1];
-    float ss[NSLICE];
-#pragma unroll
-    for (int s = 0; s < NSLICE; ++s) {
-        load_tile<P, 1, HT, true>(x[s], hs, tok, n_tokens, d, s, lane);
-        float a = 0.0f;
-#pragma unroll
-        for (int i = 0; i < P; ++i) a = fmaf(x[s][i][0], x[s][i][0], a);
-        ss[s] = a;
-    }
-    const float total = canonical_row_total(ss, lane);
-    const float ms = total / (float)d;
-    const float rs = 1.0f / __builtin_sqrtf(ms + eps);
-    if (lane == 0) rs_out[tok] = rs;
-    float *orow = normed + (size_t)tok * d;
-#pragma unroll
-    for (int s = 0; s < NSLICE; ++s) {
-        float w1[P][1];
-        load_tile<P, 1, float, true>(w1, w, 0, 1, d, s, lane);
-#pragma unroll
-        for (int i = 0; i < P; ++i)
-            store_run_ending_at<P>(orow, s, lane, i, [&](int k) { return (x[s][k][0] * rs) * (1.0f + w1[k][0]); });
-    }
-}
-
-template <typename HT>
-__device__ __forceinline__ HT narrow(float v);
-template <>
-__device__ __forceinline__ _Float16 narrow<_Float16>(float v) { return (_Float16)v; }
-template <>
-__device__ __forceinline__ float narrow<float>(float v) { return v; }
-template <>
-__device__ __forceinline__ uint16_t narrow<uint16_t>(float v)   // round-to-nearest-even bf16 (as torch .to(bfloat16))
-{
-    return __builtin_bit_cast(uint16_t, (__bf16)v);
-}
-
-template <typename HT>
-__global__ void __launch_bounds__(256)
-gemma_denorm_patch_kernel(const float *q, const float *w, const float *rs, long long n_tokens, int d, int seq_len,
-                          int skip_bos, HT *hs_inout, float *new_out)
-{
-    const int lane = threadIdx.x & 63;
-    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= n_tokens) return;
-    const bool bos = skip_bos && (tok % seq_len) == 0;
-    const float r = rs[tok];
-    const float *qrow = q + (size_t)tok * d;
-    HT *hrow = hs_inout + (size_t)tok * d;
-    float *nrow = new_out ? new_out + (size_t)tok * d : nullptr;
-    for (int e = lane; e < d; e += 64) {
-        float v;
-        if (bos) v = widen<HT>(hrow[e]);                       // q_out[:, 0] = hs[:, 0]  (model.py:285-286)
-        else {
-            const float t = qrow[e] / (1.0f + w[e]);           // rqae/llm.py:69
-            v = t / r;                                          // rqae/llm.py:70-72
-        }
-        if (nrow) nrow[e] = v;
-        if (!bos) hrow[e] = narrow<HT>(v);                      // output[0].data.copy_(q_out)  (model.py:289)
-    }
-}
-
-// Vector form of the patch kernel (d % 4 == 0, 16-byte aligned rows): float4 in, 4 elements of the LLM's
-// dtype out per lane and step.  Same arithmetic as gemma_denorm_patch_kernel.
-template <typename HT>
-__global__ void __launch_bounds__(256)
-gemma_denorm_patch_vec_kernel(const float *q, const float *w, const float *rs, long long n_tokens, int d, int seq_len,
-                              int skip_bos, HT *hs_inout, float *new_out)
-{
-    typedef typename VecOf<HT, 4>::type H4;
-    const int lane = threadIdx.x & 63;
-    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= n_tokens) return;
-    const bool bos = skip_bos && (tok % seq_len) == 0;      // wave-uniform
-    const float r = rs[tok];
-    const float *qrow = q + (size_t)tok * d;
-    HT *hrow = hs_inout + (size_t)tok * d;
-    float *nrow = new_out ? new_out + (size_t)tok * d : nullptr;
-    if (bos) {                                               // q_out[:, 0] = hs[:, 0]  (model.py:285-286): hs stays
-        if (nrow)
-            for (int e0 = 4 * lane; e0 < d; e0 += 256) {
-                const H4 h = *reinterpret_cast<const H4 *>(hrow + e0);
-                *reinterpret_cast<f4 *>(nrow + e0) = (f4){widen<HT>(h.x), widen<HT>(h.y), widen<HT>(h.z), widen<HT>(h.w)};
-            }
-        return;
-    }
-    for (int e0 = 4 * lane; e0 < d; e0 += 256) {
-        const f4 qv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(qrow + e0));
-        const f4 wv = *reinterpret_cast<const f4 *>(w + e0);
-        f4 v;
-        v.x = (qv.x / (1.0f + wv.x)) / r; v.y = (qv.y / (1.0f + wv.y)) / r;   // rqae/llm.py:69-72
-        v.z = (qv.z / (1.0f + wv.z)) / r; v.w = (qv.w / (1.0f + wv.w)) / r;
-        if (nrow) *reinterpret_cast<f4 *>(nrow + e0) = v;
-        H4 o;
-        o.x = narrow<HT>(v.x); o.y = narrow<HT>(v.y); o.z = narrow<HT>(v.z); o.w = narrow<HT>(v.w);
-        *reinterpret_cast<H4 *>(hrow + e0) = o;             // output[0].data.copy_(q_out)  (model.py:289)
-    }
-}
-
-// =============================================================== feature intensity
-// RQAEFeature.intensity (rqae/feature.py:102-129): for every token n and every requested level l
-//     sims[n][m] = codebook_sims[center[m], code[n][m]] * w[m]            (fp16 product)
-//     out[n][l]  = fp16( fp16(sum_{m<=l} sims[n][m]) / wcum[l] )           (fp32 running sum, sequential)
-// with torch-CPU's fp16 semantics written out (oracle/oracle.py:intensity restates them; bit-equal to the
-// reference's output).  One lane = one token, levels strictly in order (the sum is a sequential fp32 chain, so
-// there is no parallel scan).  HBM-bound on the code matrix: a wave reads its 64 tokens x TL levels tile with
-// fully coalesced 16-byte loads (one tile ahead, in registers), transposes it through LDS and walks its own
-// row; the per-level table rows (codebook_sims[center[m], :], K fp16 each) sit in LDS a chunk of levels at a time.
-struct IntensityParams {
-    const _Float16 *table;    // [M][K]  = codebook_sims[center[m], :]
-    const _Float16 *w, *wcum; // [M]
-    const void *idx;
-    const int *layers;        // [n_layers] device
-    _Float16 *out;            // [n_tokens][n_layers]
-    long long n_tokens;
-    int nq, M, K, LC, n_layers, vec_ok;
-};
-
-__global__ void intensity_prepare_kernel(const _Float16 *sims, const int *center, const _Float16 *w, int M, int K,
-                                         _Float16 *table, _Float16 *wcum)
-{
-    const size_t n = (size_t)M * K;
-    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(u / K), k = (int)(u % K);
-        table[u] = sims[(size_t)center[m] * K + k];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {   // layer_weights[:M].cumsum(): fp32 accumulator, fp16 prefixes
-        float acc = 0.0f;
-        for (int m = 0; m < M; ++m) {
-            acc += (float)w[m];
-            wcum[m] = (_Float16)acc;
-        }
-    }
-}
-
-template <typename IT>
-__global__ void __launch_bounds__(256)
-intensity_kernel(const IntensityParams p)
-{
-    constexpr int TL = 16;                          // levels per index tile
-    constexpr int EPC = 16 / sizeof(IT);            // index elements per 16-byte chunk
-    constexpr int CPR = TL / EPC;                   // chunks per tile row
-    constexpr int RS = CPR + 1;                     // row stride in chunks (odd: conflict-free row reads)
-    typedef IT ITV __attribute__((ext_vector_type(EPC)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tab_bytes = ((p.LC * p.K * 2 + 15) & ~15);
-    _Float16 *tab = reinterpret_cast<_Float16 *>(smem_raw);                       // [LC][K]
-    float *wf = reinterpret_cast<float *>(smem_raw + tab_bytes);                   // [32] w, [32] wcum
-    unsigned *omask = reinterpret_cast<unsigned *>(wf + 64);                       // output levels of the tile
-    ITV *tiles = reinterpret_cast<ITV *>(smem_raw + tab_bytes + 64 * 4 + 16);      // [4 waves][64 rows][RS]
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long tokw = (long long)blockIdx.x * 256 + wave * 64;
-    const long long tok = tokw + lane;
-    ITV *tile = tiles + (size_t)wave * 64 * RS;
-    const IT *idx = reinterpret_cast<const IT *>(p.idx);
-
-    // this lane's share of the wave's tile: chunk c of row r for the CPR load steps
-    auto load_tile = [&](int m0, ITV (&regs)[CPR]) {
-#pragma unroll
-        for (int j = 0; j < CPR; ++j) {
-            const int u = j * 64 + lane, r = u / CPR, c = u % CPR;
-            long long t = tokw + r;
-            if (t >= p.n_tokens) t = p.n_tokens - 1;
-            const IT *src = idx + (size_t)t * p.nq + m0 + c * EPC;
-            if (p.vec_ok && m0 + TL <= p.nq) {
-                regs[j] = *reinterpret_cast<const ITV *>(src);
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) regs[j][e] = (m0 + c * EPC + e < p.nq) ? src[e] : (IT)0;
-            }
-        }
-    };
-    // table chunk [c0, c0+LC) -> registers (whole 16-byte pieces; at most 12 per thread for a 48-KiB chunk)
-    constexpr int TPT = 12;
-    auto load_table = [&](int c0, f4 (&tregs)[TPT]) {
-        const int nlev = (p.M - c0) < p.LC ? (p.M - c0) : p.LC;
-        const int n16 = (nlev * p.K * 2 + 15) / 16;
-        const f4 *src = reinterpret_cast<const f4 *>(p.table + (size_t)c0 * p.K);
-#pragma unroll
-        for (int j = 0; j < TPT; ++j) {
-            const int u = j * 256 + threadIdx.x;
-            if (u < n16) tregs[j] = src[u];
-        }
-    };
-    ITV regs[CPR];
-    f4 tregs[TPT];
-    load_tile(0, regs);
-    load_table(0, tregs);
-    float acc = 0.0f;
-
-    for (int c0 = 0; c0 < p.M; c0 += p.LC) {
-        const int m0 = c0 & ~(TL - 1);
-        const bool new_tile = c0 == m0;
-        __syncthreads();                                  // previous table chunk (and tile) no longer read
-        if (new_tile) {
-#pragma unroll
-            for (int j = 0; j < CPR; ++j) {
-                const int u = j * 64 + lane, r = u / CPR, c = u % CPR;
-                tile[r * RS + c] = regs[j];
-            }
-            if (threadIdx.x < 64) {                       // weights of the tile's levels; which of them are outputs
-                const int m = m0 + threadIdx.x;
-                bool hit = false;
-                if (threadIdx.x < TL) {
-                    wf[threadIdx.x] = m < p.M ? (float)p.w[m] : 0.0f;
-                    wf[32 + threadIdx.x] = m < p.M ? (float)p.wcum[m] : 1.0f;
-                    for (int j = 0; j < p.n_layers; ++j) hit |= p.layers[j] == m;
-                }
-                const unsigned long long b = __ballot(hit);
-                if (threadIdx.x == 0) *omask = (unsigned)b;
-            }
-        }
-        {
-            const int nlev = (p.M - c0) < p.LC ? (p.M - c0) : p.LC;
-            const int n16 = (nlev * p.K * 2 + 15) / 16;
-#pragma unroll
-            for (int j = 0; j < TPT; ++j) {
-                const int u = j * 256 + threadIdx.x;
-                if (u < n16) reinterpret_cast<f4 *>(tab)[u] = tregs[j];
-            }
-        }
-        __syncthreads();
-        if (c0 + p.LC < p.M) {                            // next chunk (and tile): in flight behind this one
-            load_table(c0 + p.LC, tregs);
-            if (((c0 + p.LC) & (TL - 1)) == 0) load_tile(c0 + p.LC, regs);
-        }
-        const unsigned mask = *omask;
-        int hi = c0 + p.LC;
-        if (hi > p.M) hi = p.M;
-        auto emit = [&](int m, int rel) __attribute__((always_inline)) {   // output level: wave-uniform branch
-            const _Float16 pref = (_Float16)acc;                              // cumsum's prefixes are fp16
-            const _Float16 o = (_Float16)((float)pref / wf[32 + rel]);
-            if (tok < p.n_tokens)
-                for (int j = 0; j < p.n_layers; ++j)
-                    if (p.layers[j] == m) p.out[(size_t)tok * p.n_layers + j] = o;
-        };
-        int m = c0;
-        // whole 16-byte groups of codes: one row read, EPC gathers in flight together, then the sequential sum
-        for (; m + EPC <= hi && ((m - m0) % EPC) == 0; m += EPC) {
-            const int rel = m - m0;
-            const ITV codes = tile[lane * RS + rel / EPC];
-            float sv[EPC], wv[EPC];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) sv[e] = (float)tab[(m + e - c0) * p.K + (int)codes[e]];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) wv[e] = wf[rel + e];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const _Float16 prod = (_Float16)(sv[e] * wv[e]);             // sims *= layer_weights
-                acc += (float)prod;                                            // cumsum: fp32 accumulator
-                if ((mask >> (rel + e)) & 1u) emit(m + e, rel + e);
-            }
-        }
-        for (; m < hi; ++m) {
-            const int rel = m - m0;
-            const IT code = reinterpret_cast<const IT *>(tile + lane * RS)[rel];
-            const float sv = (float)tab[(m - c0) * p.K + (int)code];
-            const _Float16 prod = (_Float16)(sv * wf[rel]);
-            acc += (float)prod;
-            if ((mask >> rel) & 1u) emit(m, rel);
-        }
-    }
-}
+namespace {
 
 struct PackedView {
     const Header *hdr;

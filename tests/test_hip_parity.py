@@ -581,3 +581,24 @@ def test_encode_gemma_folds_the_norm(cfgname, dtype, n):
     assert np.array_equal(rs.cpu().numpy()[0], rs_o) and np.array_equal(normed.cpu().numpy()[0], normed_o)
     q_o, idx_o = oracle.forward(normed_o, w)
     assert np.array_equal(idx.cpu().numpy()[0], idx_o) and np.array_equal(q.cpu().numpy()[0], q_o)
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 31, 33, 63, 255, 257, 1023, 4097])
+def test_tile_boundaries_against_oracle(n):
+    """Token counts around the 8-token wave and 16-token workgroup tiles, fp32 / bf16 / fp16 in turn: codes and
+    reconstruction bit for bit against the oracle, decode of the codes too."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    dtype = [torch.float32, torch.bfloat16, torch.float16][n % 3]
+    x = torch.from_numpy(synth.activations(100 + n, n, cfg["dim"])).to(dtype)
+    xf = x.float().numpy()
+    with torch.inference_mode():
+        q, idx = m(x.to(DEV).view(1, n, -1))
+        dec = m.decode(idx)
+        codes_only = m.encode(x.to(DEV).view(1, n, -1))
+    torch.cuda.synchronize()
+    q_o, idx_o = oracle.forward(xf, w)
+    assert np.array_equal(idx[0].cpu().numpy(), idx_o) and np.array_equal(codes_only[0].cpu().numpy(), idx_o)
+    assert np.array_equal(q[0].cpu().numpy(), q_o)
+    assert np.array_equal(dec[0].cpu().numpy(), oracle.decode(idx_o, w))

@@ -379,7 +379,7 @@ int dispatch_decode(int P, int c, const DecParams &p, bool from_idx, hipStream_t
         if (P == 9 && c == 5) return launch_decode<9, 5, 16, false>(p, from_idx, stream);
         if (P == 9 && c == 4) return launch_decode<9, 4, 16, false>(p, from_idx, stream);
         if (P == 1 && c == 4) return launch_decode<1, 4, 16, false>(p, from_idx, stream);
-        if (P == 14 && c == 13) return launch_decode<14, 13, 4, false>(p, from_idx, stream);
+        if (P == 14 && c == 13) return launch_decode<14, 13, 2, false>(p, from_idx, stream);   // (4 tokens per wave parks values in AGPRs)
     }
     if (P <= 8) return launch_decode<8, 16, 4, true>(p, from_idx, stream);
     return launch_decode<32, 16, 4, true>(p, from_idx, stream);

@@ -13,6 +13,11 @@ __global__ void __launch_bounds__(512, 2)
 rqae_encode_lds_kernel(const EncParams p)
 {
     constexpr int TPW = 8, NW = 8, TG = 16, TQ = 2, JW = 8, NG = 2, NPAIR = 4;
+#ifdef RQAE_ABLATE_BUILD   // timing experiments only (tools/timeline.py): RQAE_HIP_ABLATE bits skip parts of the kernel
+    const int ABLATE = p.ablate;
+#else
+    constexpr int ABLATE = 0;
+#endif
     static_assert(C <= 8, "quantise phase uses 8 lanes per token");
     constexpr int QOUT = rec_out_quads(P, C), QIN = rec_in_quads(P, C), NQ = QOUT + QIN;
     constexpr int NPIECE = NSLICE * NQ;         // 1-KiB pieces in one pass record
@@ -435,8 +440,8 @@ rqae_encode_lds_kernel(const EncParams p)
         TL_STAMP();
         __syncthreads();
         TL_STAMP();
-        if (!(p.ablate & 1)) dma_begin(l + 1);
-        if (!(p.ablate & 2)) quantise(l, bin_own);
+        if (!(ABLATE & 1)) dma_begin(l + 1);
+        if (!(ABLATE & 2)) quantise(l, bin_own);
         else dma_flush();
         TL_STAMP();
         slot_end();                                       // cvs published, record l+1 landed
@@ -459,7 +464,7 @@ rqae_encode_lds_kernel(const EncParams p)
     }
     for (int l = 1; l + 1 < p.levels; ++l) {
         bin_own = bias_of(l + 1);
-        if (!(p.ablate & 4)) {                            // apply level l, project onto level l+1
+        if (!(ABLATE & 4)) {                              // apply level l, project onto level l+1
             pass_out(F{}, F{});
             pass_in();
         }

@@ -18,7 +18,7 @@ if not os.path.exists(TL_SO) or any(os.path.getmtime(TL_SO) < os.path.getmtime(o
     os.makedirs(os.path.dirname(TL_SO), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
                     "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-                    "-DRQAE_SINGLE_TU", "-DRQAE_TIMELINE", "-DRQAE_EXPERIMENT_ONLY_95", SRC, "-o", TL_SO],     # one translation unit
+                    "-DRQAE_SINGLE_TU", "-DRQAE_TIMELINE", "-DRQAE_ABLATE_BUILD", "-DRQAE_EXPERIMENT_ONLY_95", SRC, "-o", TL_SO],     # one translation unit
                    check=True, cwd=os.path.dirname(SRC))
 nat.SO_PATH = TL_SO
 from rqae_amd import RQAE, synth

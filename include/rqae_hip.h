@@ -142,6 +142,29 @@ int rqae_hip_intensity(const void *table, const void *layer_weights, const void 
                        const void *indices, int idx_dtype, int64_t n_tokens, int nq, const int *layers_dev,
                        int n_layers, void *out, void *stream);
 
+/*
+ * The model's cached tables (rqae/model.py:133-178): what RQAEFeature and the demo server read
+ * from the module besides the codes.  All pointers are device pointers; the fp16 tables are row-major.
+ *
+ *   rqae_hip_codebook_sims      replaces RQAE.codebook_sims (rqae/model.py:133-143):
+ *       out[K][K] fp16 = F.normalize(codebook0) @ F.normalize(codebook0).T with torch-CPU's orders written out
+ *       (same bits as the reference on CPU).  codebook0 is codebook[0], [K][c] fp32.
+ *   rqae_hip_subfeatures        replaces RQAE.subfeatures (rqae/model.py:145-156):
+ *       out[L][K][d] fp32 = lin_out_l(codebook[l]) (same bits as the reference on CPU).
+ *       codebook [L][K][c], w_out [L][d][c], b_out [L][d], all fp32.
+ *   rqae_hip_subfeature_sims    replaces RQAE.subfeature_sims and RQAE.layer_norms (rqae/model.py:158-178):
+ *       sims_out[L][K][K] fp16 = cosine of subfeature rows, layer_norms_out[L] fp32 = mean column norm of
+ *       W_out[l]; either may be NULL.  Computed from the (c+1)x(c+1) Gram matrix of [W_out[l] | b_out[l]] in
+ *       fp64 -- the (L,K,d) subfeatures are never materialised.  scratch: rqae_hip_tables_scratch_bytes(L,K,c)
+ *       bytes, 8-byte aligned, owned by the caller for the duration of the call's stream work.
+ */
+int rqae_hip_codebook_sims(const float *codebook0, int K, int c, void *out, void *stream);
+int rqae_hip_subfeatures(const float *codebook, const float *w_out, const float *b_out, int L, int K, int c, int d,
+                         float *out, void *stream);
+size_t rqae_hip_tables_scratch_bytes(int L, int K, int c);
+int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const float *b_out, int L, int K, int c, int d,
+                             void *scratch, void *sims_out, float *layer_norms_out, void *stream);
+
 /* Human-readable name of the encode kernel variant chosen for a shape. */
 int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);
 

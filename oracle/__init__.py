@@ -15,4 +15,8 @@ from .oracle import (  # noqa: F401
     gemma_norm_canonical,
     gemma_denorm_canonical,
     intensity,
+    codebook_sims,
+    subfeatures,
+    subfeature_sims,
+    layer_norms,
 )

@@ -40,6 +40,15 @@ def _load():
         lib.rqae_oracle_decode.argtypes = [ip, i64, i, i, i, i, i, fp, fp, fp, bp, fp, i]
         lib.rqae_oracle_decode.restype = i
         lib.rqae_oracle_max_threads.restype = i
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.rqae_oracle_codebook_sims.argtypes = [fp, i, i, fp]
+        lib.rqae_oracle_codebook_sims.restype = None
+        lib.rqae_oracle_subfeatures.argtypes = [fp, fp, fp, i, i, i, i, fp]
+        lib.rqae_oracle_subfeatures.restype = None
+        lib.rqae_oracle_subfeature_sims_level.argtypes = [fp, i, i, dp]
+        lib.rqae_oracle_subfeature_sims_level.restype = None
+        lib.rqae_oracle_layer_norms.argtypes = [fp, i, i, i, dp]
+        lib.rqae_oracle_layer_norms.restype = None
         _lib = lib
     return _lib
 
@@ -239,3 +248,45 @@ def intensity(codebook_sims, center, layer_weights, token_indices, layers):
         wc[m] = np.float16(wacc)
     out = (pref.astype(np.float32) / wc.astype(np.float32)).astype(np.float16)
     return out[..., layers]
+
+
+# --- the model's cached tables ------------------------------------------------
+
+def codebook_sims(codebook0):
+    """RQAE.codebook_sims (rqae/model.py:133-143): (K, K) fp16, same bits as the reference on CPU."""
+    cb, cbp = _f(codebook0)
+    K, c = cb.shape
+    out = np.empty((K, K), np.float32)
+    _load().rqae_oracle_codebook_sims(cbp, K, c, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out.astype(np.float16)
+
+
+def subfeatures(w):
+    """RQAE.subfeatures (rqae/model.py:145-156): (L, K, d) fp32, same bits as the reference on CPU."""
+    cb, cbp = _f(w["codebook"]); wo, wop = _f(w["w_out"]); bo, bop = _f(w["b_out"])
+    L, K, c = cb.shape
+    d = wo.shape[1]
+    out = np.empty((L, K, d), np.float32)
+    _load().rqae_oracle_subfeatures(cbp, wop, bop, L, K, c, d, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
+def subfeature_sims(w, levels=None):
+    """RQAE.subfeature_sims (rqae/model.py:158-168) in double precision: (L, K, K) float64 (see rqae_oracle.c)."""
+    sub = subfeatures(w)
+    L, K, d = sub.shape
+    levels = range(L) if levels is None else levels
+    out = np.empty((len(levels), K, K), np.float64)
+    for i, l in enumerate(levels):
+        s, sp = _f(sub[l])
+        _load().rqae_oracle_subfeature_sims_level(sp, K, d, out[i].ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return out
+
+
+def layer_norms(w):
+    """RQAE.layer_norms (rqae/model.py:170-178) in double precision: (L,) float64."""
+    wo, wop = _f(w["w_out"])
+    L, d, c = wo.shape
+    out = np.empty(L, np.float64)
+    _load().rqae_oracle_layer_norms(wop, L, c, d, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return out

@@ -360,6 +360,96 @@ int rqae_oracle_decode(const int64_t *idx, int64_t n_tokens, int idx_levels, int
     return used;
 }
 
+/*
+ * The cached tables of the model (rqae/model.py:133-178), the rows SURVEY 8(f) ranks f4.
+ *
+ * codebook_sims (model.py:141-142): F.normalize(cb0, dim=-1) @ F.normalize(cb0, dim=-1).T.
+ * F.normalize divides by max(||row||, 1e-12) with the norm ordered as x.norm(dim=-1) (aten_norm2
+ * above); the (K,c)@(c,K) product is a k-ordered fma chain from +0, like `x @ codebook.T` of
+ * quantize.  Output fp32; the caller rounds to fp16 (model.py:142).
+ */
+void rqae_oracle_codebook_sims(const float *cb0, int K, int c, float *out)
+{
+    float *unit = (float *)malloc(sizeof(float) * (size_t)K * c);
+    for (int n = 0; n < K; ++n) {
+        float nr = aten_norm2(cb0 + (size_t)n * c, c);
+        if (!(nr > 1e-12f)) nr = 1e-12f;
+        for (int k = 0; k < c; ++k) unit[(size_t)n * c + k] = cb0[(size_t)n * c + k] / nr;
+    }
+#pragma omp parallel for schedule(static)
+    for (int a = 0; a < K; ++a)
+        for (int b = 0; b < K; ++b) {
+            float acc = 0.0f;
+            for (int k = 0; k < c; ++k) acc = fmaf(unit[(size_t)a * c + k], unit[(size_t)b * c + k], acc);
+            out[(size_t)a * K + b] = acc;
+        }
+    free(unit);
+}
+
+/*
+ * subfeatures (model.py:145-156): out[l][n][:] = lin_out_l(codebook[l][n]) -- the same chain as the
+ * level step of decode (fma chain over k from +0, then + bias), on codebook[l] rather than codebook[0].
+ */
+void rqae_oracle_subfeatures(const float *cb, const float *w_out, const float *b_out, int L, int K,
+                             int c, int d, float *out)
+{
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int l = 0; l < L; ++l)
+        for (int n = 0; n < K; ++n) {
+            const float *row = cb + ((size_t)l * K + n) * c;
+            float *o = out + ((size_t)l * K + n) * d;
+            for (int e = 0; e < d; ++e) {
+                const float *w = w_out + ((size_t)l * d + e) * c;
+                float y = 0.0f;
+                for (int k = 0; k < c; ++k) y = fmaf(row[k], w[k], y);
+                o[e] = y + b_out[(size_t)l * d + e];
+            }
+        }
+}
+
+/*
+ * subfeature_sims (model.py:158-168) and layer_norms (model.py:170-178).  The reference's
+ * (K,d)@(d,K) product runs in whatever order the BLAS picks, so there are no reference bits to follow:
+ * this is the value in double precision from the fp32 subfeatures above (cosine of rows, each row divided
+ * by max(norm, 1e-12)), which the fp16 result of the reference must equal to within its own fp32 rounding.
+ * sub is [K][d] for one level; out fp64 [K][K].
+ */
+void rqae_oracle_subfeature_sims_level(const float *sub, int K, int d, double *out)
+{
+    double *inv = (double *)malloc(sizeof(double) * K);
+    for (int n = 0; n < K; ++n) {
+        double s = 0.0;
+        for (int e = 0; e < d; ++e) s += (double)sub[(size_t)n * d + e] * sub[(size_t)n * d + e];
+        s = sqrt(s);
+        inv[n] = 1.0 / (s > 1e-12 ? s : 1e-12);
+    }
+#pragma omp parallel for schedule(static)
+    for (int a = 0; a < K; ++a)
+        for (int b = 0; b < K; ++b) {
+            double s = 0.0;
+            for (int e = 0; e < d; ++e) s += (double)sub[(size_t)a * d + e] * sub[(size_t)b * d + e];
+            out[(size_t)a * K + b] = s * inv[a] * inv[b];
+        }
+    free(inv);
+}
+
+/* layer_norms[l] = mean over the c columns of ||W_out[l][:, k]||_2 (model.py:174), in double. */
+void rqae_oracle_layer_norms(const float *w_out, int L, int c, int d, double *out)
+{
+    for (int l = 0; l < L; ++l) {
+        double m = 0.0;
+        for (int k = 0; k < c; ++k) {
+            double s = 0.0;
+            for (int e = 0; e < d; ++e) {
+                double v = w_out[((size_t)l * d + e) * c + k];
+                s += v * v;
+            }
+            m += sqrt(s);
+        }
+        out[l] = m / c;
+    }
+}
+
 int rqae_oracle_max_threads(void)
 {
 #ifdef _OPENMP

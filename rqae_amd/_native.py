@@ -34,6 +34,10 @@ SYMBOLS = (
     "rqae_hip_gemma_denorm_patch",
     "rqae_hip_intensity_prepare",
     "rqae_hip_intensity",
+    "rqae_hip_codebook_sims",
+    "rqae_hip_subfeatures",
+    "rqae_hip_tables_scratch_bytes",
+    "rqae_hip_subfeature_sims",
     "rqae_hip_kernel_info",
 )
 
@@ -82,6 +86,14 @@ def lib():
     L.rqae_hip_intensity_prepare.restype = i
     L.rqae_hip_intensity.argtypes = [vp, vp, vp, i, i, vp, i, i64, i, vp, i, vp, vp]
     L.rqae_hip_intensity.restype = i
+    L.rqae_hip_codebook_sims.argtypes = [vp, i, i, vp, vp]
+    L.rqae_hip_codebook_sims.restype = i
+    L.rqae_hip_subfeatures.argtypes = [vp, vp, vp, i, i, i, i, vp, vp]
+    L.rqae_hip_subfeatures.restype = i
+    L.rqae_hip_tables_scratch_bytes.argtypes = [i, i, i]
+    L.rqae_hip_tables_scratch_bytes.restype = sz
+    L.rqae_hip_subfeature_sims.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, vp, vp]
+    L.rqae_hip_subfeature_sims.restype = i
     L.rqae_hip_kernel_info.argtypes = [i, i, i, i, ctypes.c_char_p, sz]
     L.rqae_hip_kernel_info.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
@@ -317,6 +329,57 @@ def intensity(table, w, wcum, M: int, K: int, idx2d: torch.Tensor, layers_dev: t
                                           _stream(idx2d.device))
         _check(rc, "rqae_hip_intensity")
     return out
+
+
+def _f32_dev(t: torch.Tensor, what: str) -> torch.Tensor:
+    _require_cuda(t, what)
+    return t.detach().to(torch.float32).contiguous()
+
+
+def codebook_sims(codebook0: torch.Tensor) -> torch.Tensor:
+    """[K, c] fp32 on the device -> [K, K] f16 cosine table; rqae/model.py:133-143 (the reference's CPU bits)."""
+    cb = _f32_dev(codebook0, "codebook")
+    K, c = cb.shape
+    out = torch.empty((K, K), dtype=torch.float16, device=cb.device)
+    with torch.cuda.device(cb.device):
+        rc = lib().rqae_hip_codebook_sims(cb.data_ptr(), K, c, out.data_ptr(), _stream(cb.device))
+    _check(rc, "rqae_hip_codebook_sims")
+    return out
+
+
+def subfeatures(codebook: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor) -> torch.Tensor:
+    """codebook [L, K, c], w_out [L, d, c], b_out [L, d] on the device -> [L, K, d] fp32; rqae/model.py:145-156."""
+    cb, wo, bo = _f32_dev(codebook, "codebook"), _f32_dev(w_out, "w_out"), _f32_dev(b_out, "b_out")
+    L, K, c = cb.shape
+    d = wo.shape[1]
+    if wo.shape != (L, d, c) or bo.shape != (L, d):
+        raise RuntimeError("subfeatures: w_out must be [L, d, c] and b_out [L, d]")
+    out = torch.empty((L, K, d), dtype=torch.float32, device=cb.device)
+    with torch.cuda.device(cb.device):
+        rc = lib().rqae_hip_subfeatures(cb.data_ptr(), wo.data_ptr(), bo.data_ptr(), L, K, c, d, out.data_ptr(),
+                                        _stream(cb.device))
+    _check(rc, "rqae_hip_subfeatures")
+    return out
+
+
+def subfeature_sims(codebook: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor, want_sims: bool = True):
+    """-> (sims [L, K, K] f16 or None, layer_norms [L] fp32); rqae/model.py:158-178, from the Gram matrices in fp64."""
+    cb, wo, bo = _f32_dev(codebook, "codebook"), _f32_dev(w_out, "w_out"), _f32_dev(b_out, "b_out")
+    L, K, c = cb.shape
+    d = wo.shape[1]
+    if wo.shape != (L, d, c) or bo.shape != (L, d):
+        raise RuntimeError("subfeature_sims: w_out must be [L, d, c] and b_out [L, d]")
+    nbytes = lib().rqae_hip_tables_scratch_bytes(L, K, c)
+    if nbytes == 0:
+        _check(1, "rqae_hip_tables_scratch_bytes")
+    scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=cb.device)
+    sims = torch.empty((L, K, K), dtype=torch.float16, device=cb.device) if want_sims else None
+    norms = torch.empty(L, dtype=torch.float32, device=cb.device)
+    with torch.cuda.device(cb.device):
+        rc = lib().rqae_hip_subfeature_sims(cb.data_ptr(), wo.data_ptr(), bo.data_ptr(), L, K, c, d, scratch.data_ptr(),
+                                            sims.data_ptr() if want_sims else None, norms.data_ptr(), _stream(cb.device))
+    _check(rc, "rqae_hip_subfeature_sims")
+    return sims, norms
 
 
 def kernel_info(d: int, c: int, K: int, L: int) -> str:

@@ -375,6 +375,7 @@ const char *dispatch_encode(int P, int c, const EncParams *p, hipStream_t stream
 #include "decode.hpp"
 #include "hook.hpp"
 #include "intensity.hpp"
+#include "tables.hpp"
 
 namespace {
 
@@ -725,6 +726,88 @@ int rqae_hip_intensity(const void *table, const void *layer_weights, const void 
     if (idx_dtype == RQAE_IDX_I64) return go(intensity_kernel<long long>);
     if (idx_dtype == RQAE_IDX_I32) return go(intensity_kernel<int>);
     return go(intensity_kernel<uint16_t>);
+}
+
+int rqae_hip_codebook_sims(const float *codebook0, int K, int c, void *out, void *stream)
+{
+    if (!codebook0 || !out) return fail("codebook_sims: null pointer");
+    if (K < 1 || c < 1 || c > MAX_C) return fail("codebook_sims: bad sizes K=%d c=%d (need 1<=c<=%d)", K, c, MAX_C);
+    const dim3 grid((unsigned)((K + 255) / 256), (unsigned)((K + 31) / 32));
+    if (grid.y > 65535u) return fail("codebook_sims: K=%d too large for one launch", K);
+    hipLaunchKernelGGL(codebook_sims_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), codebook0, K, c,
+                       (_Float16 *)out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rqae_hip_subfeatures(const float *codebook, const float *w_out, const float *b_out, int L, int K, int c, int d,
+                         float *out, void *stream)
+{
+    if (!codebook || !w_out || !b_out || !out) return fail("subfeatures: null pointer");
+    if (!shape_ok(d, c, K, L) || L > 65535) return fail("subfeatures: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int RPB = 64;
+    const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const int per_wave = vec ? 256 : 64;
+    const dim3 grid((unsigned)((d + per_wave - 1) / per_wave), (unsigned)((K + RPB - 1) / RPB), (unsigned)L);
+    if (grid.y > 65535u) return fail("subfeatures: K=%d too large for one launch", K);
+#define SUBF(CB, V) hipLaunchKernelGGL((subfeatures_kernel<CB, V>), grid, dim3(256), 0, s, codebook, w_out, b_out, K, c, d, RPB, out)
+    if (vec) {
+        if (c <= 5) SUBF(5, 4);
+        else if (c <= 8) SUBF(8, 4);
+        else SUBF(MAX_C, 4);
+    } else {
+        if (c <= 8) SUBF(8, 1);
+        else SUBF(MAX_C, 1);
+    }
+#undef SUBF
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t rqae_hip_tables_scratch_bytes(int L, int K, int c)
+{
+    if (L < 1 || K < 1 || c < 1 || c > MAX_C) {
+        fail("tables_scratch_bytes: bad sizes L=%d K=%d c=%d", L, K, c);
+        return 0;
+    }
+    return (size_t)L * tables_level_doubles(K, c) * sizeof(double);
+}
+
+int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const float *b_out, int L, int K, int c, int d,
+                             void *scratch, void *sims_out, float *layer_norms_out, void *stream)
+{
+    if (!codebook || !w_out || !b_out || !scratch) return fail("subfeature_sims: null pointer");
+    if (!sims_out && !layer_norms_out) return fail("subfeature_sims: nothing to compute");
+    if (!shape_ok(d, c, K, L) || L > 65535) return fail("subfeature_sims: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    if ((reinterpret_cast<uintptr_t>(scratch) & 7) != 0) return fail("subfeature_sims: scratch must be 8-byte aligned");
+    if (sims_out && (reinterpret_cast<uintptr_t>(sims_out) & 15) != 0) return fail("subfeature_sims: sims_out must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(tables_prep_kernel, dim3((unsigned)L), dim3(256), 0, s, codebook, w_out, b_out, K, c, d,
+                       (double *)scratch, layer_norms_out);
+    HIP_TRY(hipGetLastError());
+    if (!sims_out) return 0;
+    const int MB = c + 1 <= 5 ? 5 : c + 1 <= 6 ? 6 : c + 1 <= 9 ? 9 : c + 1 <= 14 ? 14 : MAX_C + 1;
+    const int NC = MB <= 9 ? 8 : 4;                 // columns per lane: NC * MB doubles of registers
+    const int SEG = 256 * NC, W = K < SEG ? K : SEG, ncg = (W + NC - 1) / NC, nsub = 256 / ncg;
+    const int TR = K < 128 ? K : 128;
+    int RC = 4 * nsub;                              // four rows per lane between two barriers
+    if (RC > 64) RC = 64;
+    if (RC > TR) RC = TR;
+    const size_t lds = (size_t)TR * MB * sizeof(double) + (size_t)RC * ((((size_t)W * 2 + 15) & ~(size_t)15) + 16);
+    const dim3 grid((unsigned)((K + TR - 1) / TR), (unsigned)L, (unsigned)((K + SEG - 1) / SEG));
+    if (grid.z > 65535u) return fail("subfeature_sims: K=%d too large for one launch", K);
+#define SIMS(MBV) hipLaunchKernelGGL((subfeature_sims_kernel<MBV, (MBV <= 9 ? 8 : 4)>), grid, dim3(256), lds, s, codebook, (const double *)scratch, K, c, TR, RC, (_Float16 *)sims_out)
+    switch (MB) {
+    case 5: SIMS(5); break;
+    case 6: SIMS(6); break;
+    case 9: SIMS(9); break;
+    case 14: SIMS(14); break;
+    default: SIMS(MAX_C + 1); break;
+    }
+#undef SIMS
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 }  // extern "C"

@@ -225,40 +225,68 @@ class RQAE(nn.Module):
         self.codebook.data.copy_(cb / cb.norm(dim=-1, keepdim=True))
         self._packed = None  # .data writes do not bump the parameter's version counter
 
-    # -------------------------------------------------- cached metadata (not hot)
+    # -------------------------------------------------- cached tables
+    # On a ROCm device the tables come from the HIP kernels of csrc/tables.hpp (no torch fallback there); a module
+    # still on the CPU (before .to("cuda"), as RQAEFeature.from_quantizer may see it) computes them as the
+    # reference does.  codebook_sims and subfeatures have the reference's CPU bits either way.
+    def _on_device(self) -> bool:
+        return self.codebook.device.type == "cuda"
+
+    def _table_inputs(self):
+        with torch.no_grad():
+            _, _, w_out, b_out = self._stacked()
+            return self.codebook.detach().float().contiguous(), w_out, b_out
+
     @property
     def codebook_sims(self):
         """(K, K) fp16 cosine similarities of the level-0 codebook (rqae/model.py:133-143)."""
         if "_codebook_sims" not in self.__dict__:
             if self.quantization_method != "round_fsq":
                 raise ValueError("Codebook sims only supported for round_fsq for now")
-            unit = F.normalize(self.codebook.data.detach().clone()[0], dim=-1)
-            self.__dict__["_codebook_sims"] = (unit @ unit.T).to(torch.float16)
+            if self._on_device():
+                self.__dict__["_codebook_sims"] = _native.codebook_sims(self.codebook.data[0])
+            else:
+                unit = F.normalize(self.codebook.data.detach().clone()[0], dim=-1)
+                self.__dict__["_codebook_sims"] = (unit @ unit.T).to(torch.float16)
         return self.__dict__["_codebook_sims"]
 
     @property
     def subfeatures(self):
         """(L, K, d): lin_out_l applied to codebook[l] (rqae/model.py:145-156)."""
         if "_subfeatures" not in self.__dict__:
-            self.__dict__["_subfeatures"] = torch.stack(
-                [pair[1](self.codebook[l]) for l, pair in enumerate(self.layers)])
+            if self._on_device():
+                self.__dict__["_subfeatures"] = _native.subfeatures(*self._table_inputs())
+            else:
+                self.__dict__["_subfeatures"] = torch.stack(
+                    [pair[1](self.codebook[l]) for l, pair in enumerate(self.layers)])
         return self.__dict__["_subfeatures"]
 
     @property
     def subfeature_sims(self):
-        """(L, K, K) fp16 cosine similarities between subfeatures (rqae/model.py:158-168)."""
+        """(L, K, K) fp16 cosine similarities between subfeatures (rqae/model.py:158-168).
+
+        On the device this is the quadratic form of the (c+1)x(c+1) Gram matrix in fp64 (csrc/tables.hpp); the
+        (L, K, d) subfeatures are not materialised for it."""
         if "_subfeature_sims" not in self.__dict__:
-            unit = F.normalize(self.subfeatures, dim=-1)
-            self.__dict__["_subfeature_sims"] = (unit @ unit.transpose(-1, -2)).to(torch.float16)
+            if self._on_device():
+                sims, norms = _native.subfeature_sims(*self._table_inputs())
+                self.__dict__["_subfeature_sims"] = sims
+                self.__dict__.setdefault("_layer_norms", norms)
+            else:
+                unit = F.normalize(self.subfeatures, dim=-1)
+                self.__dict__["_subfeature_sims"] = (unit @ unit.transpose(-1, -2)).to(torch.float16)
         return self.__dict__["_subfeature_sims"]
 
     @property
     def layer_norms(self):
         """(L,) mean column norm of each lin_out weight (rqae/model.py:170-178)."""
         if "_layer_norms" not in self.__dict__:
-            self.__dict__["_layer_norms"] = torch.tensor(
-                [pair[1].weight.data.norm(dim=0).mean().item() for pair in self.layers],
-                device=self.layers[0][1].weight.device)
+            if self._on_device():
+                self.__dict__["_layer_norms"] = _native.subfeature_sims(*self._table_inputs(), want_sims=False)[1]
+            else:
+                self.__dict__["_layer_norms"] = torch.tensor(
+                    [pair[1].weight.data.norm(dim=0).mean().item() for pair in self.layers],
+                    device=self.layers[0][1].weight.device)
         return self.__dict__["_layer_norms"]
 
     # ------------------------------------------------------------------ hot path

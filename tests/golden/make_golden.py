@@ -194,8 +194,40 @@ def feature_case():
     print("feat_p written", out.shape, out.dtype, os.path.getsize(os.path.join(HERE, "feat_p.npz")))
 
 
+def tables_case():
+    """The cached tables (rqae/model.py:133-178): codebook_sims, subfeatures, subfeature_sims, layer_norms."""
+    out = {}
+    cases = dict(c1=("C1", None), c2=("C2", 2), p=("P", 3), c5=("C5", 2))
+    for tag, (cfgname, levels) in cases.items():
+        cfg = dict(synth.CONFIGS[cfgname])
+        if levels:
+            cfg["num_quantizers"] = levels
+        w = synth.weights(SEED_W, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+        m = ref_model(cfg, w)
+        with torch.inference_mode():
+            sub = m.subfeatures.numpy()
+            sims = m.subfeature_sims.numpy()
+            cbs = m.codebook_sims.numpy()
+            ln = m.layer_norms.numpy()
+        K = sub.shape[1]
+        rows = sample_rows(K)
+        assert sims.dtype == np.float16 and cbs.dtype == np.float16 and ln.dtype == np.float32
+        out[tag + "_cfg"] = json.dumps(cfg)
+        out[tag + "_rows"] = rows
+        out[tag + "_subfeatures_rows"] = sub[:, rows]          # (L, rows, d) fp32
+        out[tag + "_subfeature_sims_rows"] = sims[:, rows]     # (L, rows, K) fp16
+        out[tag + "_codebook_sims_rows"] = cbs[rows]           # (rows, K) fp16
+        out[tag + "_layer_norms"] = ln
+        print(tag, sub.shape, sims.shape, cbs.shape, ln)
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), meta=json.dumps(dict(seed_w=SEED_W)), **out)
+    print("tables written", os.path.getsize(os.path.join(HERE, "tables.npz")))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "tables":
+        tables_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "feature":
         feature_case()
         sys.exit(0)
@@ -211,3 +243,4 @@ if __name__ == "__main__":
     kat_case()
     hook_case()
     feature_case()
+    tables_case()

@@ -602,3 +602,63 @@ def test_tile_boundaries_against_oracle(n):
     assert np.array_equal(idx[0].cpu().numpy(), idx_o) and np.array_equal(codes_only[0].cpu().numpy(), idx_o)
     assert np.array_equal(q[0].cpu().numpy(), q_o)
     assert np.array_equal(dec[0].cpu().numpy(), oracle.decode(idx_o, w))
+
+
+# ---------------------------------------------------------------- cached tables
+def _tables_model(g, tag):
+    import json
+    cfg = json.loads(str(g[tag + "_cfg"]))
+    w = synth.weights(g["meta"]["seed_w"], cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    return cfg, w, make_model(cfg, w), g[tag + "_rows"]
+
+
+@pytest.mark.parametrize("tag", ["c1", "c2", "p", "c5"])
+def test_tables_against_reference_and_oracle(tag):
+    """RQAE.codebook_sims / subfeatures / subfeature_sims / layer_norms on the device (csrc/tables.hpp): the first
+    two bit for bit against the reference capture and the oracle; the Gram-matrix subfeature_sims within the
+    reference's own fp32 rounding of the capture and correctly rounded against the oracle's double."""
+    g = load_golden("tables")
+    cfg, w, m, rows = _tables_model(g, tag)
+    cbs, sub = m.codebook_sims, m.subfeatures
+    sims, norms = m.subfeature_sims, m.layer_norms
+    torch.cuda.synchronize()
+    L, K = cfg["num_quantizers"], w["codebook"].shape[1]
+    assert cbs.dtype == torch.float16 and cbs.shape == (K, K) and cbs.device.type == "cuda"
+    assert sub.dtype == torch.float32 and sub.shape == (L, K, cfg["dim"])
+    assert sims.dtype == torch.float16 and sims.shape == (L, K, K) and norms.shape == (L,)
+    cbs, sub, sims, norms = cbs.cpu().numpy(), sub.cpu().numpy(), sims.cpu().numpy(), norms.cpu().numpy()
+    assert np.array_equal(cbs[rows].view(np.uint16), g[tag + "_codebook_sims_rows"].view(np.uint16))
+    assert np.array_equal(cbs.view(np.uint16), oracle.codebook_sims(w["codebook"][0]).view(np.uint16))
+    assert np.array_equal(sub[:, rows], g[tag + "_subfeatures_rows"])
+    assert np.array_equal(sub, oracle.subfeatures(w))
+    ref = g[tag + "_subfeature_sims_rows"]
+    ulp = np.spacing(np.abs(ref)).astype(np.float64)
+    assert (np.abs(sims[:, rows].astype(np.float64) - ref.astype(np.float64)) <= ulp).all()
+    assert (sims[:, rows].view(np.uint16) == ref.view(np.uint16)).mean() > 0.999
+    # the oracle's double starts from the fp32-rounded subfeatures (as the reference does), the kernel from their
+    # exact affine images: the two differ by the rounding of the subfeatures (~1e-8 relative), so the fp16 results
+    # differ only where the value sits within 5e-8 of an fp16 rounding tie
+    exact = oracle.subfeature_sims(w, levels=[L - 1])[0]
+    r16 = exact.astype(np.float16)
+    near = 0.5 * np.spacing(np.abs(r16)).astype(np.float64) - np.abs(exact - r16.astype(np.float64)) < 5e-8
+    same = sims[L - 1].view(np.uint16) == r16.view(np.uint16)
+    assert (same | near).all() and same.mean() > 0.9995
+    assert np.abs(norms / g[tag + "_layer_norms"] - 1).max() < 1e-6
+    assert np.array_equal(norms, oracle.layer_norms(w).astype(np.float32))
+
+
+def test_tables_odd_shapes():
+    """d not a multiple of 4 (scalar stores), c = 13 (the wide Gram path), K not a multiple of the column group."""
+    for d, c, size, L in [(250, 3, 3, 3), (512, 13, 2, 2), (64, 7, 2, 1)]:
+        cfg = dict(dim=d, codebook_dim=c, codebook_size=size, num_quantizers=L)
+        w = synth.weights(77, d, c, L, size)
+        m = make_model(cfg, w)
+        sub, sims, norms, cbs = m.subfeatures, m.subfeature_sims, m.layer_norms, m.codebook_sims
+        torch.cuda.synchronize()
+        assert np.array_equal(sub.cpu().numpy(), oracle.subfeatures(w))
+        assert np.array_equal(cbs.cpu().numpy().view(np.uint16), oracle.codebook_sims(w["codebook"][0]).view(np.uint16))
+        exact = oracle.subfeature_sims(w)
+        got = sims.cpu().numpy()
+        assert (np.abs(got.astype(np.float64) - exact) <= 0.5 * np.spacing(np.abs(got)).astype(np.float64) + 5e-8).all()
+        assert (got.view(np.uint16) == exact.astype(np.float16).view(np.uint16)).mean() > 0.9999
+        assert np.array_equal(norms.cpu().numpy(), oracle.layer_norms(w).astype(np.float32))

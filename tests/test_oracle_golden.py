@@ -148,3 +148,31 @@ def test_intensity_against_reference_capture():
     assert np.array_equal(out.view(np.uint16), g["intensity_default"].view(np.uint16))
     out = oracle.intensity(g["codebook_sims"], g["center"], g["layer_weights"], g["token_indices"], [3])
     assert np.array_equal(out.view(np.uint16), g["intensity_l3"].view(np.uint16))
+
+
+TABLE_CASES = ["c1", "c2", "p", "c5"]
+
+
+def _tables_case(g, tag):
+    import json
+    cfg = json.loads(str(g[tag + "_cfg"]))
+    w = synth.weights(g["meta"]["seed_w"], cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    return cfg, w, g[tag + "_rows"]
+
+
+@pytest.mark.parametrize("tag", TABLE_CASES)
+def test_tables_against_reference_capture(tag):
+    """codebook_sims and subfeatures restated with the reference's bits; subfeature_sims / layer_norms
+    (BLAS-ordered in the reference) restated in double, within the reference's own fp32 rounding of the capture."""
+    g = load_golden("tables")
+    cfg, w, rows = _tables_case(g, tag)
+    cbs = oracle.codebook_sims(w["codebook"][0])
+    assert np.array_equal(cbs[rows].view(np.uint16), g[tag + "_codebook_sims_rows"].view(np.uint16))
+    sub = oracle.subfeatures(w)
+    assert np.array_equal(sub[:, rows], g[tag + "_subfeatures_rows"])
+    ref = g[tag + "_subfeature_sims_rows"]
+    mine = oracle.subfeature_sims(w)[:, rows]
+    ulp = np.spacing(np.abs(ref)).astype(np.float64)
+    assert (np.abs(mine - ref.astype(np.float64)) <= 0.5 * ulp + 2e-6).all()        # fp16 rounding + fp32 product
+    assert (mine.astype(np.float16).view(np.uint16) == ref.view(np.uint16)).mean() > 0.999
+    assert np.abs(oracle.layer_norms(w) / g[tag + "_layer_norms"] - 1).max() < 1e-6

@@ -783,29 +783,44 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
     if ((reinterpret_cast<uintptr_t>(scratch) & 7) != 0) return fail("subfeature_sims: scratch must be 8-byte aligned");
     if (sims_out && (reinterpret_cast<uintptr_t>(sims_out) & 15) != 0) return fail("subfeature_sims: sims_out must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(tables_prep_kernel, dim3((unsigned)L), dim3(256), 0, s, codebook, w_out, b_out, K, c, d,
+    hipLaunchKernelGGL(tables_prep_kernel, dim3((unsigned)L, (unsigned)((K + 1023) / 1024)), dim3(256), 0, s, codebook, w_out, b_out, K, c, d,
                        (double *)scratch, layer_norms_out);
     HIP_TRY(hipGetLastError());
     if (!sims_out) return 0;
-    const int MB = c + 1 <= 5 ? 5 : c + 1 <= 6 ? 6 : c + 1 <= 9 ? 9 : c + 1 <= 14 ? 14 : MAX_C + 1;
-    const int NC = MB <= 9 ? 8 : 4;                 // columns per lane: NC * MB doubles of registers
-    const int SEG = 256 * NC, W = K < SEG ? K : SEG, ncg = (W + NC - 1) / NC, nsub = 256 / ncg;
-    const int TR = K < 128 ? K : 128;
-    int RC = 4 * nsub;                              // four rows per lane between two barriers
-    if (RC > 64) RC = 64;
-    if (RC > TR) RC = TR;
-    const size_t lds = (size_t)TR * MB * sizeof(double) + (size_t)RC * ((((size_t)W * 2 + 15) & ~(size_t)15) + 16);
-    const dim3 grid((unsigned)((K + TR - 1) / TR), (unsigned)L, (unsigned)((K + SEG - 1) / SEG));
-    if (grid.z > 65535u) return fail("subfeature_sims: K=%d too large for one launch", K);
-#define SIMS(MBV) hipLaunchKernelGGL((subfeature_sims_kernel<MBV, (MBV <= 9 ? 8 : 4)>), grid, dim3(256), lds, s, codebook, (const double *)scratch, K, c, TR, RC, (_Float16 *)sims_out)
-    switch (MB) {
-    case 5: SIMS(5); break;
-    case 6: SIMS(6); break;
-    case 9: SIMS(9); break;
-    case 14: SIMS(14); break;
-    default: SIMS(MAX_C + 1); break;
+    _Float16 *sims = (_Float16 *)sims_out;
+    const double *scr = (const double *)scratch;
+    if (K < 64) {
+        hipLaunchKernelGGL(subfeature_sims_small_kernel, dim3((unsigned)((K * K + 255) / 256), (unsigned)L), dim3(256), 0, s,
+                           codebook, scr, K, c, sims);
+        HIP_TRY(hipGetLastError());
+        return 0;
     }
-#undef SIMS
+    const int MB = c + 1 <= 5 ? 5 : c + 1 <= 6 ? 6 : c + 1 <= 9 ? 9 : c + 1 <= 14 ? 14 : MAX_C + 1;
+    const int NC = MB <= 9 ? 8 : 4;                 // elements per piece: NC * MB doubles of registers per lane
+    int g = K % NC, h = NC;                         // PR = NC / gcd(K, NC): rows between equal alignments
+    while (g) { const int t = h % g; h = g; g = t; }
+    const int PR = NC / h;
+    const int maxnp = (K + 2 * NC - 2) / NC;
+    int TR = MB <= 6 ? 256 : 128;                   // rows per block: fewer when that leaves the chip short of blocks
+    while (TR > 32 && (long long)L * ((K + TR - 1) / TR) * ((maxnp + 255) / 256) < 2048) TR >>= 1;
+    const int ncol = K < NC * 257 ? K : NC * 257;   // columns a block stages in LDS
+    const size_t plane = (size_t)ncol + ncol / NC + 1;   // padded column count (tables.hpp)
+    const size_t lds = ((size_t)(TR + 1) * MB + plane) * sizeof(double) + plane * c * sizeof(float);
+    const dim3 grid((unsigned)((K + TR - 1) / TR), (unsigned)L, (unsigned)((maxnp + 255) / 256));
+    if (grid.z > 65535u) return fail("subfeature_sims: K=%d too large for one launch", K);
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, codebook, scr, K, c, TR, PR, ncol, sims);
+        return 0;
+    };
+    switch (MB) {
+    case 5: if (go(subfeature_sims_kernel<5, 8>)) return 1; break;
+    case 6: if (go(subfeature_sims_kernel<6, 8>)) return 1; break;
+    case 9: if (go(subfeature_sims_kernel<9, 8>)) return 1; break;
+    case 14: if (go(subfeature_sims_kernel<14, 4>)) return 1; break;
+    default: if (go(subfeature_sims_kernel<MAX_C + 1, 4>)) return 1; break;
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -110,7 +110,8 @@ __host__ __device__ inline size_t tables_level_doubles(int K, int c)
     return m * m + (size_t)K + (size_t)K * m;
 }
 
-// tables_prep_kernel: one block per level.
+// tables_prep_kernel: blockIdx.x = level; blockIdx.y = a chunk of 1024 codebook rows (every chunk's block forms G
+// itself: d*(c+1)^2/2 fmas, cheaper than a second launch or a grid-wide wait).
 __global__ void __launch_bounds__(256)
 tables_prep_kernel(const float *__restrict__ cb, const float *__restrict__ w_out, const float *__restrict__ b_out,
                    int K, int c, int d, double *__restrict__ scratch, float *__restrict__ layer_norms)
@@ -147,17 +148,19 @@ tables_prep_kernel(const float *__restrict__ cb, const float *__restrict__ w_out
         for (int g = 0; g < groups; ++g) s += part[g * np + tid];
         sG[pa][pb] = s;
         sG[pb][pa] = s;
-        G[pa * m + pb] = s;
-        G[pb * m + pa] = s;
+        if (blockIdx.y == 0) {
+            G[pa * m + pb] = s;
+            G[pb * m + pa] = s;
+        }
     }
     __syncthreads();
-    if (tid == 0 && layer_norms) {
+    if (tid == 0 && layer_norms && blockIdx.y == 0) {
         double s = 0.0;
         for (int k = 0; k < c; ++k) s += sqrt(sG[k][k]);
         layer_norms[l] = (float)(s / c);
     }
     double *inv = G + m * m, *gv = inv + K;
-    for (int n = tid; n < K; n += 256) {
+    for (int n = blockIdx.y * 1024 + tid; n < min(K, (int)(blockIdx.y + 1) * 1024); n += 256) {
         const float *row = cb + ((size_t)l * K + n) * c;
         double v[M];
 #pragma unroll
@@ -181,52 +184,76 @@ tables_prep_kernel(const float *__restrict__ cb, const float *__restrict__ w_out
     }
 }
 
-// subfeature_sims_kernel: a block owns TR rows x one segment of up to 256*NC columns of one level.  A lane owns NC
-// consecutive columns (their v and inv in registers as doubles) and every nsub-th row; rows are done RC at a
-// time: the lanes put their fp16 results into an LDS image of the RC row segments, laid out so that LDS and
-// global addresses agree modulo 16 (rows are K*2 bytes apart in memory -- 1250 at K = 625 -- so no per-lane
-// store could be aligned), then the block writes every segment with aligned 16-byte stores and finishes its ragged
-// head and tail with 2-byte ones.  MB >= c+1 is the padded length of v (zeros beyond c+1).
+// One element of the table from the scratch block (the slow path: ragged pieces and tiny codebooks).
+__device__ __forceinline__ _Float16 sims_element(const float *__restrict__ cbl, const double *__restrict__ inv,
+                                                 const double *__restrict__ gv, int c, int row, int col)
+{
+    const int m = c + 1;
+    const double iv = inv[col];
+    double acc = 0.0;
+    for (int a = 0; a < m; ++a) acc = fma(gv[(size_t)row * m + a], (a < c ? (double)cbl[(size_t)col * c + a] : 1.0) * iv, acc);
+    return (_Float16)(float)acc;
+}
+
+// subfeature_sims_kernel: a block owns TR rows x up to 256 pieces of one level; a piece is NC consecutive fp16 of
+// the output at an NC*2-byte aligned address (NC = 8: one 16-byte store).  Rows are K*2 bytes apart in memory
+// (1250 at K = 625), so the columns a piece covers shift from row to row: row r of level l starts mis =
+// (l*K*K + r*K) mod NC elements into a piece, and piece p of that row covers columns NC*p - mis .. + NC-1.  mis
+// repeats every PR = NC / gcd(K, NC) rows, so a lane owns one piece index p, takes the rows class by class
+// (rows i0, i0+PR, ... share mis), loads the NC columns' v * inv for the class into registers (doubles, from the
+// block's LDS copy of the codebook segment) and then does one row per step: m fp64 fmas per element against the
+// row's G v * inv (LDS), fp64 -> fp32 -> fp16, one aligned store.  No barrier after the prologue.
+// The piece that straddles rows r-1 and r (when mis > 0) and the ragged end of the level's last row are written
+// element by element at the end (blockIdx.z == 0).  MB >= c+1 is the padded length of v (zeros beyond c+1).
 template <int MB, int NC>
 __global__ void __launch_bounds__(256)
 subfeature_sims_kernel(const float *__restrict__ cb, const double *__restrict__ scratch, int K, int c, int TR,
-                       int RC, _Float16 *__restrict__ out)
+                       int PR, int ncol_lds, _Float16 *__restrict__ out)
 {
-    constexpr int SEG = 256 * NC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int l = blockIdx.y, row0 = blockIdx.x * TR, seg0 = blockIdx.z * SEG, tid = threadIdx.x, m = c + 1;
-    const int nrow = min(TR, K - row0), W = min(SEG, K - seg0);        // this block's rows and columns
-    const int SR = ((W * 2 + 15) & ~15) + 16;                           // LDS bytes per row segment
-    double *gvs = reinterpret_cast<double *>(smem_raw);                 // [TR][MB]
-    unsigned char *img = smem_raw + (size_t)TR * MB * sizeof(double);   // [RC][SR]
+    const int l = blockIdx.y, row0 = blockIdx.x * TR, P0 = blockIdx.z * 256, tid = threadIdx.x, m = c + 1;
+    const int nrow = min(TR, K - row0);
+    const size_t EL = (size_t)l * K * K;                                // element offset of the level
+    const int maxnp = (K + 2 * NC - 2) / NC;                            // pieces a row can touch
+    const int ncg = min(256, maxnp - P0);
+    const int c_lo = max(0, NC * P0 - NC), c_hi = min(K, NC * (P0 + ncg));   // columns this block can need
+    double *gvs = reinterpret_cast<double *>(smem_raw) + MB;           // [-1 .. TR-1][MB]: row0-1 first (ragged pieces)
+    double *invs = gvs + (size_t)TR * MB;                               // [ncol_lds]
+    // the codebook segment, transposed, column x at word x + x/NC of its plane: a lane reads columns NC*p+q for fixed
+    // q, so consecutive lanes are NC+1 words apart and the reads are free of bank conflicts (likewise invs, doubles)
+    const int plane = ncol_lds + ncol_lds / NC + 1;
+    float *cbs = reinterpret_cast<float *>(invs + plane);               // [c][plane]
+    auto pad = [](int x) { return x + x / NC; };
     const double *G = scratch + (size_t)l * tables_level_doubles(K, c), *inv = G + m * m, *gv = inv + K;
     const float *cbl = cb + (size_t)l * K * c;
-    for (int e = tid; e < nrow * MB; e += 256) {
-        const int r = e / MB, a = e % MB;
-        gvs[e] = a < m ? gv[(size_t)(row0 + r) * m + a] : 0.0;
+    for (int e = tid - MB; e < nrow * MB; e += 256) {
+        const int r = e < 0 ? -1 : e / MB, a = e < 0 ? e + MB : e % MB;
+        gvs[e] = a < m && row0 + r >= 0 ? gv[(size_t)(row0 + r) * m + a] : 0.0;
     }
-    const int ncg = (W + NC - 1) / NC;                                  // <= 256
-    const int nsub = 256 / ncg, cg = tid % ncg, sub = tid / ncg;
-    const bool worker = sub < nsub;
-    const int col0 = seg0 + cg * NC;
-    double v[NC][MB], iv[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        const int col = min(col0 + j, K - 1);
-        iv[j] = inv[col];
-#pragma unroll
-        for (int a = 0; a < MB; ++a) {
-            const float x = cbl[min((size_t)col * c + a, (size_t)K * c - 1)];
-            v[j][a] = a < c ? (double)x : (a == c ? 1.0 : 0.0);
-        }
-    }
-    const int tpr = 256 / RC, crun = tid / tpr, clane = tid % tpr;     // copy-out: tpr lanes per row segment
+    for (int i = tid; i < c_hi - c_lo; i += 256) invs[pad(i)] = inv[c_lo + i];
+    for (int i = tid; i < (c_hi - c_lo) * c; i += 256) cbs[(i % c) * plane + pad(i / c)] = cbl[(size_t)c_lo * c + i];
     __syncthreads();
-    for (int rc0 = 0; rc0 < nrow; rc0 += RC) {
-        const int nrc = min(RC, nrow - rc0);
-        if (worker)
-            for (int r = sub; r < nrc; r += nsub) {
-                const double *g = gvs + (rc0 + r) * MB;
+    const int nsub = 256 / ncg, cg = tid % ncg, sub = tid / ncg;
+    if (sub < nsub) {
+        const int p = P0 + cg;
+        for (int i0 = 0; i0 < PR && i0 < nrow; ++i0) {
+            const int mis = (int)((EL + (size_t)(row0 + i0) * K) % NC);
+            const int cfirst = NC * p - mis;
+            if (cfirst < 0 || cfirst + NC > K) continue;               // ragged pieces: below
+            double v[NC][MB];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int li = pad(cfirst + j - c_lo);
+                const double iv = invs[li];
+#pragma unroll
+                for (int a = 0; a < MB; ++a) {
+                    const float x = cbs[min(a, c - 1) * plane + li];
+                    v[j][a] = (a < c ? (double)x : (a == c ? 1.0 : 0.0)) * iv;
+                }
+            }
+            _Float16 *dst = out + EL + (size_t)row0 * K + cfirst;       // + i * K: NC-aligned for rows of this class
+            for (int i = i0 + PR * sub; i < nrow; i += PR * nsub) {
+                const double *g = gvs + i * MB;
                 double acc[NC];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) acc[j] = 0.0;
@@ -236,32 +263,48 @@ subfeature_sims_kernel(const float *__restrict__ cb, const double *__restrict__ 
 #pragma unroll
                     for (int j = 0; j < NC; ++j) acc[j] = fma(ga, v[j][a], acc[j]);
                 }
-                const size_t e0 = ((size_t)l * K + row0 + rc0 + r) * K + seg0;      // element offset of the segment
-                _Float16 *dst = reinterpret_cast<_Float16 *>(img + (size_t)r * SR) + (e0 & 7) + cg * NC;
+                typedef _Float16 hvec __attribute__((ext_vector_type(NC)));
+                hvec h;
 #pragma unroll
-                for (int j = 0; j < NC; ++j) dst[j] = (_Float16)(float)(acc[j] * iv[j]);
-            }
-        __syncthreads();
-        if (crun < nrc) {
-            const size_t e0 = ((size_t)l * K + row0 + rc0 + crun) * K + seg0;
-            const int mis = (int)(e0 & 7);                               // elements before e0 in its 16-byte piece
-            const int npiece = (mis + W + 7) / 8;
-            _Float16 *gbase = out + (e0 - mis);                          // 16-byte aligned (out is)
-            const unsigned char *lrow = img + (size_t)crun * SR;
-            for (int pc = clane; pc < npiece; pc += tpr) {
-                const int lo = pc * 8, hi = lo + 8;                      // elements of the piece, relative to gbase
-                if (lo >= mis && hi <= mis + W) {
-                    const f4 t = *reinterpret_cast<const f4 *>(lrow + (size_t)pc * 16);
-                    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(gbase + lo));
-                } else {
-                    const _Float16 *lp = reinterpret_cast<const _Float16 *>(lrow) + lo;
-                    for (int j = 0; j < 8; ++j)
-                        if (lo + j >= mis && lo + j < mis + W) gbase[lo + j] = lp[j];
-                }
+                for (int j = 0; j < NC; ++j) h[j] = (_Float16)(float)acc[j];
+                *reinterpret_cast<hvec *>(dst + (size_t)i * K) = h;
             }
         }
-        __syncthreads();
     }
+    if (blockIdx.z == 0) {
+        auto element = [&](int i, int col) -> _Float16 {               // row row0 + i (i >= -1) x column col
+            const bool in_lds = col >= c_lo && col < c_hi;
+            const double iv = in_lds ? invs[pad(col - c_lo)] : inv[col];
+            double acc = 0.0;
+            for (int a = 0; a < m; ++a) {
+                const double x = a < c ? (double)(in_lds ? cbs[a * plane + pad(col - c_lo)] : cbl[(size_t)col * c + a]) : 1.0;
+                acc = fma(gvs[i * MB + a], x * iv, acc);
+            }
+            return (_Float16)(float)acc;
+        };
+        for (int t = tid; t < nrow * NC; t += 256) {
+            const int i = t / NC, j = t % NC, r = row0 + i;
+            const size_t e_r = EL + (size_t)r * K;
+            const int mis = (int)(e_r % NC);
+            if (mis > 0 && (j >= mis || r > 0))                         // the piece shared with row r-1
+                out[e_r - mis + j] = j < mis ? element(i - 1, K - mis + j) : element(i, j - mis);
+            const int tailn = (int)((e_r + K) % NC);
+            if (r == K - 1 && j < tailn)                                // the level's ragged end
+                out[e_r + K - tailn + j] = element(i, K - tailn + j);
+        }
+    }
+}
+
+// K < 64: one lane per element.
+__global__ void __launch_bounds__(256)
+subfeature_sims_small_kernel(const float *__restrict__ cb, const double *__restrict__ scratch, int K, int c,
+                             _Float16 *__restrict__ out)
+{
+    const int l = blockIdx.y, m = c + 1;
+    const double *G = scratch + (size_t)l * tables_level_doubles(K, c), *inv = G + m * m, *gv = inv + K;
+    const float *cbl = cb + (size_t)l * K * c;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < K * K; e += gridDim.x * 256)
+        out[(size_t)l * K * K + e] = sims_element(cbl, inv, gv, c, e / K, e % K);
 }
 
 }  // namespace

@@ -15,6 +15,8 @@ __global__ void __launch_bounds__(1024) probe(long long *out, float *sink, int i
     __syncthreads();
     f2 a[16];
     for (int i = 0; i < 16; ++i) a[i] = (f2){seed + i, seed - i};
+    f2 bb[16], cc[16];
+    for (int i = 0; i < 16; ++i) { bb[i] = (f2){seed * i, seed + 2 * i}; cc[i] = (f2){seed - 3 * i, seed * 0.5f * i}; }
     f2 x = {seed, seed * 0.5f};
     f2 w = {seed * 0.25f, seed * 0.125f};
     f2 sx = {__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, seed))),
@@ -102,6 +104,42 @@ __global__ void __launch_bounds__(1024) probe(long long *out, float *sink, int i
 #define S(i) asm volatile("v_fma_f32 %0, %1, %2, %0\n\tv_fma_f32 %3, %1, %2, %3" : "+v"(a[i].x), "+v"(a[i].y) : "v"(x.x), "v"(w.x));
             S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
 #undef S
+        } else if (MODE == 16) {  // v_fma_f64, 16 independent (a[i] reinterpreted as a double)
+#define S(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(w));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+        } else if (MODE == 17) {  // v_cvt_f32_f64
+#define S(i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i].x) : "v"(x));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+        } else if (MODE == 18) {  // v_cvt_f16_f32
+#define S(i) asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(a[i].x) : "v"(x.x));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+        } else if (MODE == 19) {  // v_fma_f64 with 8 chains of 2
+#define S(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[i & 7]) : "v"(x), "v"(w));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+        } else if (MODE == 20) {  // v_fma_f64, every operand a different register pair
+#define S(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[i]) : "v"(bb[i]), "v"(cc[i]));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+        } else if (MODE == 21) {  // v_pk_fma_f32, every operand a different register pair
+#define S(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(bb[i]), "v"(cc[i]));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+        } else if (MODE == 22) {  // v_pk_fma_f32 acc and weights distinct, x shared + broadcast (the pass's form)
+#define S(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(bb[i]), "v"(x));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+        } else if (MODE == 23) {  // v_fma_f64: accumulators distinct, one operand shared (the table kernel's form)
+#define S(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(cc[i]));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
+        } else if (MODE == 24) {  // v_fma_f32, every operand a different register
+#define S(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].x) : "v"(bb[i].x), "v"(cc[i].y));
+            S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
+#undef S
         } else if (MODE == 9) {   // v_mov_b32 (cheap VALU)
 #define S(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i].x) : "v"(x.x));
             S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15)
@@ -112,7 +150,7 @@ __global__ void __launch_bounds__(1024) probe(long long *out, float *sink, int i
     float acc = q.x + s1;
     for (int i = 0; i < 8; ++i) acc += c4[i].x + c4[i].w;
     for (int i = 0; i < 4; ++i) acc += c16[i][0] + c16[i][15];
-    for (int i = 0; i < 16; ++i) acc += a[i].x + a[i].y;
+    for (int i = 0; i < 16; ++i) acc += a[i].x + a[i].y + bb[i].x + cc[i].y;
     if (acc == 12345.678f) sink[0] = acc;
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -154,5 +192,14 @@ int main()
     run<13>("mfma 16x16x1 x16, 4 chains", d_out, d_sink);
     run<14>("16 pk_fma + 4 mfma 16x16x1 (per 16 pk)", d_out, d_sink);
     run<15>("32 v_fma_f32 (per 16 pairs)", d_out, d_sink);
+    run<16>("v_fma_f64 x16 independent", d_out, d_sink);
+    run<19>("v_fma_f64 8 chains of 2", d_out, d_sink);
+    run<20>("v_fma_f64 all operands distinct", d_out, d_sink);
+    run<23>("v_fma_f64 acc + one operand distinct", d_out, d_sink);
+    run<21>("v_pk_fma_f32 all operands distinct", d_out, d_sink);
+    run<22>("v_pk_fma_f32 acc + w distinct, x bcast", d_out, d_sink);
+    run<24>("v_fma_f32 all operands distinct", d_out, d_sink);
+    run<17>("v_cvt_f32_f64", d_out, d_sink);
+    run<18>("v_cvt_f16_f32", d_out, d_sink);
     return 0;
 }

@@ -77,8 +77,8 @@ def cpu_baseline(w, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tokens", type=int, default=262144, help="tokens per GPU per step")
     ap.add_argument("--codes-only", action="store_true", help="time RQAE.encode (no reconstruction written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -78,8 +78,11 @@ class RQAEFeature:
 
     def load_model(self, rqae):
         self.rqae = rqae
-        self.layer_weights = torch.tensor(
-            [l[1].weight.data.norm(dim=0).mean().item() for l in rqae.layers]).to(torch.float16)
+        if rqae.codebook.is_cuda:    # RQAE.layer_norms: one kernel instead of a sync per level
+            self.layer_weights = rqae.layer_norms.to(torch.float16).cpu()
+        else:
+            self.layer_weights = torch.tensor(
+                [l[1].weight.data.norm(dim=0).mean().item() for l in rqae.layers]).to(torch.float16)
         self._prepared = None
         return self
 

@@ -191,37 +191,37 @@ int launch_decode(const DecParams &p, bool from_idx, hipStream_t stream)
 // NBUF = 1: one buffer, 66 KB of LDS and <= 128 VGPRs, so TWO workgroups share a CU and cover each other's load and
 //           barrier waits (the kernel is VALU-bound once those are hidden).
 template <int P, int C, bool FROM_IDX, int NBUF>
-__global__ void __launch_bounds__(512, NBUF == 1 ? 4 : 2)
+__global__ void __launch_bounds__(512, 4)
 rqae_decode_lds_kernel(const DecParams p)
 {
-    constexpr int TPW = 8, NW = 8, TG = 16, NPAIR = 4, NG = 2, LCH = 32;
+    constexpr int TPW = 8, NW = 8, TG = 64, NPAIR = 4, NG = 2, LCH = 8;
     constexpr int NQ = rec_quads(P, C);          // quads per lane per slice in a pass record
     constexpr int QD = rec_out_quads(P, C);      // its leading quads: the packed {w_out[0..C-1], b_out} stream
     constexpr int W = C + 1;
-    constexpr int BUF = NSLICE * QD * 256;       // floats per weight buffer
+    constexpr int BUF = QD * 256;                // floats per weight buffer: one slice of one level
     constexpr int dp = 256 * P;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wbuf = smem;                          // [NBUF][slice][QD][lane][4]
+    float *wbuf = smem;                          // [NBUF][QD][lane][4]
     float *cvl = wbuf + NBUF * BUF;                 // [LCH][C][TG]  (token pairs contiguous)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slice = wave & 3, half = wave >> 2;
-    const long long tok0 = (long long)blockIdx.x * TG;
-    const long long tokw = tok0 + half * TPW;
+    // decode is elementwise in (token, element): a workgroup owns ONE slice (a quarter of d) of 64 tokens, its
+    // 8 waves 8 tokens each, so a level's weights cross L2 -> LDS once per 64 tokens and fit in 14 KB
+    const int slice = blockIdx.x & 3;
+    const long long tok0 = (long long)(blockIdx.x >> 2) * TG;
+    const long long tokw = tok0 + wave * TPW;
     const bool full_tile = (tokw + TPW <= p.n_tokens) && (p.d == dp) && p.aligned16;
     const unsigned wbuf_addr = lds_addr_of(wbuf);
 
     auto level_on = [&](int l) { return ((p.mask[l >> 5] >> (l & 31)) & 1u) != 0; };
     auto next_on = [&](int l) { while (l < p.nlev && !level_on(l)) ++l; return l; };   // uniform scalar loop
-    // lin_out quads of level l (record l+1) -> buffer b; the 8 waves share the (slice, i) chunks
+    // lin_out quads of level l (record l+1), this slice -> buffer b; the 8 waves share the pieces
     auto issue_dma = [&](int l, int b) {
-        const float *rec = p.rec_p + (size_t)(l + 1) * NSLICE * NQ * 256;
-        for (int pc = wave; pc < NSLICE * QD; pc += NW) {
-            const int s = pc / QD, q = pc - s * QD;
-            dma_pieces<1>(rec + (size_t)(s * NQ + q) * 256, wbuf_addr + (b * BUF + pc * 256) * 4, lane * 16);
-        }
+        const float *rec = p.rec_p + ((size_t)(l + 1) * NSLICE + slice) * NQ * 256;
+        for (int pc = wave; pc < QD; pc += NW)
+            dma_pieces<1>(rec + (size_t)pc * 256, wbuf_addr + (b * BUF + pc * 256) * 4, lane * 16);
     };
 
     f2 acc[P][NPAIR];
@@ -267,18 +267,17 @@ rqae_decode_lds_kernel(const DecParams p)
         __syncthreads();                                      // weights of level l + codebook values visible
         // next selected level loads behind this one: one piece per element step (a burst of all pieces waits
         // on the TA's address queue, see the encode kernel)
-        int dpc = (NBUF == 2 && ln < p.nlev) ? wave : NSLICE * QD;
-        const float *drec = p.rec_p + (size_t)(ln + 1) * NSLICE * NQ * 256;
+        int dpc = (NBUF == 2 && ln < p.nlev) ? wave : QD;
+        const float *drec = p.rec_p + ((size_t)(ln + 1) * NSLICE + slice) * NQ * 256;
         auto dma_step = [&]() __attribute__((always_inline)) {
-            if (dpc < NSLICE * QD) {
-                const int s = dpc / QD, q = dpc - s * QD;
-                dma_pieces<1>(drec + (size_t)(s * NQ + q) * 256, wbuf_addr + ((buf ^ 1) * BUF + dpc * 256) * 4, lane * 16);
+            if (dpc < QD) {
+                dma_pieces<1>(drec + (size_t)dpc * 256, wbuf_addr + ((buf ^ 1) * BUF + dpc * 256) * 4, lane * 16);
                 dpc += NW;
             }
         };
 
-        const f4 *wl = reinterpret_cast<const f4 *>(wbuf + buf * BUF) + (size_t)slice * QD * 64 + lane;
-        const float *cvp = cvl + (l - staged_from) * C * TG + half * TPW;
+        const f4 *wl = reinterpret_cast<const f4 *>(wbuf + buf * BUF) + lane;
+        const float *cvp = cvl + (l - staged_from) * C * TG + wave * TPW;
         // element step outermost: every weight quad is read from LDS once for the wave's 8 tokens
         f2 cv2[NG][2][C];
 #pragma unroll
@@ -318,7 +317,7 @@ rqae_decode_lds_kernel(const DecParams p)
                     else acc[i][2 * g + pr] = acc[i][2 * g + pr] + yy[g][pr];
                 }
         }
-        while (dpc < NSLICE * QD) dma_step();                 // more pieces per wave than element steps
+        while (dpc < QD) dma_step();                          // more pieces per wave than element steps
         first = false;
         l = ln;
         if constexpr (NBUF == 2) buf ^= 1;
@@ -344,10 +343,10 @@ template <int P, int C>
 int launch_decode_lds(const DecParams &p, bool from_idx, hipStream_t stream)
 {
     constexpr int QD = rec_out_quads(P, C);
-    const char *nb = getenv("RQAE_HIP_DECODE_NBUF");     // 2 = the double-buffered form (measured slower: 1.42 vs 1.16 ms)
-    const int nbuf = nb && atoi(nb) == 2 ? 2 : 1;
-    const size_t lds = sizeof(float) * ((size_t)nbuf * NSLICE * QD * 256 + 32 * C * 16);
-    const long long nblk = (p.n_tokens + 15) / 16;
+    const char *nb = getenv("RQAE_HIP_DECODE_NBUF");     // 1 = single weight buffer (a barrier + exposed load per level)
+    const int nbuf = nb && atoi(nb) == 1 ? 1 : 2;
+    const size_t lds = sizeof(float) * ((size_t)nbuf * QD * 256 + 8 * C * 64);
+    const long long nblk = NSLICE * ((p.n_tokens + 63) / 64);
     if (nblk > 0x7fffffffLL) return fail("decode: too many tokens for one launch");
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024)

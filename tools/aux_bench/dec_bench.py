@@ -16,6 +16,6 @@ m=RQAE(**cfg).eval(); m.load_state_dict(synth.state_dict_from_weights(w)); m=m.t
 n=262144
 x=bench.synth_batch(n,torch.device("cuda"),1000).view(1,n,-1)
 with torch.inference_mode(): q,idx=m(x)
-td=t(lambda: m.decode(idx)); print(f"NBUF={os.environ.get('RQAE_HIP_DECODE_NBUF','1')} decode C2 {n} tok: {td:.3f} ms  {n/td/1e3:.1f} Mtok/s  out {n*9216/td/1e6:.0f} GB/s")
+td=t(lambda: m.decode(idx)); print(f"NBUF={os.environ.get('RQAE_HIP_DECODE_NBUF','2')} decode C2 {n} tok: {td:.3f} ms  {n/td/1e3:.1f} Mtok/s  out {n*9216/td/1e6:.0f} GB/s")
 i16=idx.to(torch.uint16)
 td=t(lambda: m.decode(i16)); print(f"   uint16 idx: {td:.3f} ms")

@@ -280,15 +280,14 @@ rqae_decode_lds_kernel(const DecParams p)
         const float *cvp = cvl + (l - staged_from) * C * TG + wave * TPW;
         // element step outermost: every weight quad is read from LDS once for the wave's 8 tokens
         f2 cv2[NG][2][C];
+        const float cv_lane = lane < C * TPW ? cvp[(lane / TPW) * TG + (lane % TPW)] : 0.0f;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const f2 v = *reinterpret_cast<const f2 *>(cvp + k * TG + 4 * g + 2 * pr);
-                    cv2[g][pr][k] = (f2){lane_bcast_first(v.x), lane_bcast_first(v.y)};
-                }
+                for (int k = 0; k < C; ++k)   // lane k*8 + t holds the value of (k, token t): one LDS read per level
+                    cv2[g][pr][k] = (f2){lane_bcast(cv_lane, k * TPW + 4 * g + 2 * pr), lane_bcast(cv_lane, k * TPW + 4 * g + 2 * pr + 1)};
         asm volatile("s_nop 3" ::: "memory");   // v_readfirstlane -> SGPR read by the asm below
         f4 wq[QD];
 #pragma unroll

@@ -509,15 +509,15 @@ def test_intensity_matches_oracle(L, cbs, c, n, layers):
     assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
 
 
-def test_decode_double_buffered_form(monkeypatch):
-    """RQAE_HIP_DECODE_NBUF=2 selects the double-buffered decode kernel (one workgroup per CU): same bits."""
+def test_decode_single_buffer_form(monkeypatch):
+    """RQAE_HIP_DECODE_NBUF=1 selects the single-weight-buffer decode kernel (default: double-buffered): same bits."""
     g = load_golden("fwd_c2")
     cfg, w, _ = case_inputs(g)
     m = make_model(cfg, w)
     idx = torch.from_numpy(g["codes"].astype(np.int64)).to(DEV).view(1, -1, g["codes"].shape[-1])
     with torch.inference_mode():
         d1 = m.decode(idx)
-        monkeypatch.setenv("RQAE_HIP_DECODE_NBUF", "2")
+        monkeypatch.setenv("RQAE_HIP_DECODE_NBUF", "1")
         d2 = m.decode(idx)
         d3 = m.decode(idx, layers=[0, 2])
         monkeypatch.delenv("RQAE_HIP_DECODE_NBUF")
@@ -662,3 +662,31 @@ def test_tables_odd_shapes():
         assert (np.abs(got.astype(np.float64) - exact) <= 0.5 * np.spacing(np.abs(got)).astype(np.float64) + 5e-8).all()
         assert (got.view(np.uint16) == exact.astype(np.float16).view(np.uint16)).mean() > 0.9999
         assert np.array_equal(norms.cpu().numpy(), oracle.layer_norms(w).astype(np.float32))
+
+
+def test_random_shapes_against_oracle():
+    """Sixteen seeded random (d, c, codebook_size, depth, n) through whatever kernel the dispatcher picks: codes,
+    reconstruction, decode and a decode of a level subset bit for bit against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(20260103))
+    for case in range(16):
+        c = int(rng.integers(1, 9))
+        size = int(rng.integers(2, 5 if c <= 4 else 3))
+        while size ** c > 4096:
+            c -= 1
+        d = int(rng.choice([int(rng.integers(3, 700)), 256, 512, 1024, 2304]))
+        L = int(rng.integers(1, 6))
+        n = int(rng.integers(1, 400))
+        cfg = dict(dim=d, codebook_dim=c, codebook_size=size, num_quantizers=L)
+        w = synth.weights(1000 + case, d, c, L, size)
+        x = synth.activations(2000 + case, n, d)
+        m = make_model(cfg, w)
+        q, idx = run_forward(m, x)
+        q_o, idx_o = oracle.forward(x, w)
+        assert np.array_equal(idx, idx_o), cfg
+        assert np.array_equal(q, q_o), cfg
+        keep = sorted(set(int(v) for v in rng.integers(0, L, size=2)))
+        with torch.inference_mode():
+            it = torch.from_numpy(idx).to(DEV).view(1, n, L)
+            dec, dec_sub = m.decode(it), m.decode(it, layers=keep)
+        assert np.array_equal(dec[0].cpu().numpy(), oracle.decode(idx_o, w)), cfg
+        assert np.array_equal(dec_sub[0].cpu().numpy(), oracle.decode(idx_o, w, layers=keep)), cfg

@@ -44,8 +44,13 @@ rqae_encode_lds_kernel(const EncParams p)
     if (tl_on) tl_buf[wave * 64 + lane] = 0;
     TL_STAMP();
 #endif
-    const long long tok0 = (long long)blockIdx.x * TG;
-    const long long tokw = tok0 + half * TPW;
+    // Codes-only launches are persistent: one workgroup per CU (the LDS footprint allows no more) walks the
+    // 16-token tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the level-0 codebook image stays in LDS and the
+    // workgroup launch and its first instruction fetches are paid once per CU instead of once per tile (2.68 ->
+    // 2.60 ms).  With the reconstruction the loop's live scalars push hipcc into spilling SGPRs inside the sweeps
+    // (740 more v_readlane, 2.98 -> 3.40 ms), so that instantiation keeps one tile per workgroup.
+    constexpr bool PERSIST = !RECON;
+    const int ntiles = (int)((p.n_tokens + TG - 1) / TG);      // (the launcher bounds it)
 
     const bool shared_cb = p.hdr->shared_cb != 0;
     const int nchunk = (p.K + p.kch - 1) / p.kch;
@@ -80,14 +85,22 @@ rqae_encode_lds_kernel(const EncParams p)
     };
     auto dma_flush = [&]() { while (dma_next < dma_end) dma_trip(); };
 
-    {   // record 0: only its lin_in part is read
+    int tile = blockIdx.x;
+    do {
+    const long long tok0 = (long long)tile * TG;
+    const long long tokw = tok0 + half * TPW;
+    const bool first_tile = tile == (int)blockIdx.x;
+    {   // record 0: only its lin_in part is read (that part of `wts` was last read before the previous tile's last
+        // quantise phase, i.e. two barriers ago)
         for (int s = 0; s < NSLICE; ++s)
             for (int q = QOUT + wave; q < NQ; q += NW)
                 dma_pieces<1>(p.rec_p + (s * NQ + q) * 256, wts_addr + (s * NQ + q) * 1024, lane * 16);
         if (nchunk == 1) {   // level-0 codebook: its LDS image by DMA -- no registers, no wait in front of the x loads
-            const unsigned cbl_addr = lds_addr_of(cbl);
-            for (int pc = wave; pc < p.cb_img_pieces; pc += NW)
-                dma_pieces<1>(p.cb_img + pc * 256, cbl_addr + pc * 1024, lane * 16);
+            if (first_tile || !stage_once) {   // (a shared codebook that fits stays for every tile)
+                const unsigned cbl_addr = lds_addr_of(cbl);
+                for (int pc = wave; pc < p.cb_img_pieces; pc += NW)
+                    dma_pieces<1>(p.cb_img + pc * 256, cbl_addr + pc * 1024, lane * 16);
+            }
         } else {
             stage_rows<C>(cbl, p.cb, p.kch);
         }
@@ -498,6 +511,7 @@ rqae_encode_lds_kernel(const EncParams p)
             }
         }
     }
+    } while (PERSIST && (tile += gridDim.x) < ntiles);
 }
 
 template <int P, int C>
@@ -529,8 +543,22 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
     const size_t cbf = kch >= p.K ? (size_t)p.cb_img_pieces * 256 : (size_t)cb_lds_floats(C, rows);   // whole pieces when DMA-staged
     const size_t lds = fixed + sizeof(float) * cbf;
 #endif
-    const long long nblk = (p.n_tokens + TG - 1) / TG;
+    long long nblk = (p.n_tokens + TG - 1) / TG;
     if (nblk > 0x7fffffffLL) return fail("encode: too many tokens for one launch");
+#ifndef RQAE_TIMELINE   // (the timeline build stamps one tile per workgroup)
+    if (!p.q_out) {   // persistent workgroups: as many as can be resident (LDS allows floor(160 KB / lds) per CU), each walks tiles
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        long long per_cu = lds > 0 ? (160 * 1024) / (long long)lds : 1;   // LDS; at most 4 by wave slots (8 waves each)
+        if (per_cu > 4) per_cu = 4;
+        const long long resident = (long long)n_cu * per_cu;
+        if (resident >= 1 && nblk > resident) nblk = resident;
+    }
+#endif
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

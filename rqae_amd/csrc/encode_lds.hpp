@@ -8,11 +8,14 @@ namespace {
 
 // NORM: x is the hooked LLM layer's output; the Gemma RMSNorm of RQAE.hook (rqae/model.py:279, rqae/llm.py:65-66)
 // is applied while the tile is in registers (rqae_hip_encode_gemma), normed never exists in HBM.
-template <int P, int C, bool RECON, bool MFMA, bool NORM = false>
-__global__ void __launch_bounds__(512, 2)
+// NH: token halves of 8 tokens (4 waves each).  2 with the reconstruction (its registers allow 2 waves per SIMD);
+// the codes-only kernel of d = 2304 runs 3 (12 waves, 24 tokens per workgroup, 168 VGPRs): the latency-bound
+// quantise phase then serves 24 tokens per level instead of 16 and the sweeps issue at the 3-wave rate.
+template <int P, int C, bool RECON, bool MFMA, bool NORM = false, int NH = 2>
+__global__ void __launch_bounds__(256 * NH, NH)
 rqae_encode_lds_kernel(const EncParams p)
 {
-    constexpr int TPW = 8, NW = 8, TG = 16, TQ = 2, JW = 8, NG = 2, NPAIR = 4;
+    constexpr int TPW = 8, NW = 4 * NH, TG = TPW * NH, TQ = 2, JW = 8, NG = 2, NPAIR = 4;
 #ifdef RQAE_ABLATE_BUILD   // timing experiments only (tools/timeline.py): RQAE_HIP_ABLATE bits skip parts of the kernel
     const int ABLATE = p.ablate;
 #else
@@ -517,7 +520,12 @@ rqae_encode_lds_kernel(const EncParams p)
 template <int P, int C>
 int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
 {
-    constexpr int TG = 16;
+#if defined(RQAE_TU_MAIN) && !defined(RQAE_TIMELINE)
+    const int NHsel = (!p.q_out && !use_mfma && !p.norm_w) ? 3 : 2;   // codes only: 12 waves x 8 tokens
+#else
+    const int NHsel = 2;
+#endif
+    const int TG = 8 * NHsel;
     EncParams q = p;
     const size_t fixed = sizeof(float) * ((size_t)NSLICE * rec_quads(P, C) * 256 + NSLICE * TG * C + ((TG * C + 3) & ~3));
     const size_t cb_budget = 160 * 1024 - fixed - 1024;
@@ -555,6 +563,7 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
         }
         long long per_cu = lds > 0 ? (160 * 1024) / (long long)lds : 1;   // LDS; at most 4 by wave slots (8 waves each)
         if (per_cu > 4) per_cu = 4;
+        if (NHsel == 3 && per_cu > 2) per_cu = 2;
         const long long resident = (long long)n_cu * per_cu;
         if (resident >= 1 && nblk > resident) nblk = resident;
     }
@@ -563,7 +572,7 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, stream, q);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256 * NHsel), lds, stream, q);
         HIP_TRY(hipGetLastError());
         return 0;
     };
@@ -589,7 +598,11 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
 #endif
 #if defined(RQAE_TU_MAIN) || defined(RQAE_SINGLE_TU)
     if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, false>);
+#if defined(RQAE_TU_MAIN) && !defined(RQAE_TIMELINE)
+    return go(rqae_encode_lds_kernel<P, C, false, false, false, 3>);
+#else
     return go(rqae_encode_lds_kernel<P, C, false, false>);
+#endif
 #else
     if constexpr (P != 9) {
         if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, false>);

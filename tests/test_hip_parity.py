@@ -583,10 +583,11 @@ def test_encode_gemma_folds_the_norm(cfgname, dtype, n):
     assert np.array_equal(idx.cpu().numpy()[0], idx_o) and np.array_equal(q.cpu().numpy()[0], q_o)
 
 
-@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 31, 33, 63, 255, 257, 1023, 4097])
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 33, 47, 49, 63, 255, 257, 1023, 4097, 6151])
 def test_tile_boundaries_against_oracle(n):
-    """Token counts around the 8-token wave and 16-token workgroup tiles, fp32 / bf16 / fp16 in turn: codes and
-    reconstruction bit for bit against the oracle, decode of the codes too."""
+    """Token counts around the 8-token wave and the workgroup tiles (16 tokens with the reconstruction, 24 codes-only;
+    6151 tokens = 257 codes-only tiles, one more than the persistent launch has workgroups on 256 CUs), fp32 / bf16 /
+    fp16 in turn: codes and reconstruction bit for bit against the oracle, decode of the codes too."""
     cfg = synth.CONFIGS["C2"]
     w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
     m = make_model(cfg, w)

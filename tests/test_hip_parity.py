@@ -691,3 +691,34 @@ def test_random_shapes_against_oracle():
             dec, dec_sub = m.decode(it), m.decode(it, layers=keep)
         assert np.array_equal(dec[0].cpu().numpy(), oracle.decode(idx_o, w)), cfg
         assert np.array_equal(dec_sub[0].cpu().numpy(), oracle.decode(idx_o, w, layers=keep)), cfg
+
+
+def test_c_abi_from_a_c_program(tmp_path):
+    """The boundary without Python in the process: tests/c_abi/host_smoke.c (C11, gcc, HIP runtime for memory only)
+    packs, encodes and decodes through include/rqae_hip.h; its outputs equal the oracle's bit for bit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "rqae_amd", "csrc")
+    exe = str(tmp_path / "host_smoke")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "host_smoke.c"),
+                    "-L" + csrc, "-lrqae_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib",
+                    "-Wl,-rpath," + csrc, "-o", exe], check=True)
+    cfg = synth.CONFIGS["C2"]
+    d, c, L = cfg["dim"], cfg["codebook_dim"], 3
+    w = synth.weights(4321, d, c, L, cfg["codebook_size"])
+    K = w["codebook"].shape[1]
+    n = 333
+    x = synth.activations(77, n, d)
+    for name, arr in [("w_in", w["w_in"]), ("b_in", w["b_in"]), ("cb", w["codebook"]), ("w_out", w["w_out"]),
+                      ("b_out", w["b_out"]), ("x", x)]:
+        np.ascontiguousarray(arr, dtype=np.float32).tofile(tmp_path / (name + ".bin"))
+    (tmp_path / "meta.txt").write_text(f"{d} {c} {K} {L} {n} {L}\n")
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    idx = np.fromfile(tmp_path / "idx.bin", dtype=np.int64).reshape(n, L)
+    q = np.fromfile(tmp_path / "q.bin", dtype=np.float32).reshape(n, d)
+    dec = np.fromfile(tmp_path / "dec.bin", dtype=np.float32).reshape(n, d)
+    q_o, idx_o = oracle.forward(x, w)
+    assert np.array_equal(idx, idx_o) and np.array_equal(q, q_o)
+    assert np.array_equal(dec, oracle.decode(idx_o, w))

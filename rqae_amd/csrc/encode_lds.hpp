@@ -50,8 +50,9 @@ rqae_encode_lds_kernel(const EncParams p)
     // Codes-only launches are persistent: one workgroup per CU (the LDS footprint allows no more) walks the
     // 16-token tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the level-0 codebook image stays in LDS and the
     // workgroup launch and its first instruction fetches are paid once per CU instead of once per tile (2.68 ->
-    // 2.60 ms).  With the reconstruction the loop's live scalars push hipcc into spilling SGPRs inside the sweeps
-    // (740 more v_readlane, 2.98 -> 3.40 ms), so that instantiation keeps one tile per workgroup.
+    // 2.60 ms).  With the reconstruction the loop keeps the kernel arguments live across its back-edge and hipcc
+    // then spills SGPRs inside the sweeps (720 more v_readlane, 2.98 -> 3.40 ms; the same with the tile index in
+    // a VGPR), so that instantiation keeps one tile per workgroup.
     constexpr bool PERSIST = !RECON;
     const int ntiles = (int)((p.n_tokens + TG - 1) / TG);      // (the launcher bounds it)
 

@@ -157,13 +157,16 @@ int rqae_hip_intensity(const void *table, const void *layer_weights, const void 
  *       W_out[l]; either may be NULL.  Computed from the (c+1)x(c+1) Gram matrix of [W_out[l] | b_out[l]] in
  *       fp64 -- the (L,K,d) subfeatures are never materialised.  scratch: rqae_hip_tables_scratch_bytes(L,K,c)
  *       bytes, 8-byte aligned, owned by the caller for the duration of the call's stream work.
+ *       scale_by_layer_norms != 0 writes what the demo server keeps after `sims *= model.layer_norms[:, None, None]`
+ *       (demo/server/server.py:101-112): fp16(float(fp16 cosine) * layer_norms[l]) -- one pass instead of two.
  */
 int rqae_hip_codebook_sims(const float *codebook0, int K, int c, void *out, void *stream);
 int rqae_hip_subfeatures(const float *codebook, const float *w_out, const float *b_out, int L, int K, int c, int d,
                          float *out, void *stream);
 size_t rqae_hip_tables_scratch_bytes(int L, int K, int c);
 int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const float *b_out, int L, int K, int c, int d,
-                             void *scratch, void *sims_out, float *layer_norms_out, void *stream);
+                             void *scratch, void *sims_out, float *layer_norms_out, int scale_by_layer_norms,
+                             void *stream);
 
 /* Human-readable name of the encode kernel variant chosen for a shape. */
 int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);

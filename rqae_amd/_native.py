@@ -92,7 +92,7 @@ def lib():
     L.rqae_hip_subfeatures.restype = i
     L.rqae_hip_tables_scratch_bytes.argtypes = [i, i, i]
     L.rqae_hip_tables_scratch_bytes.restype = sz
-    L.rqae_hip_subfeature_sims.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, vp, vp]
+    L.rqae_hip_subfeature_sims.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, vp, i, vp]
     L.rqae_hip_subfeature_sims.restype = i
     L.rqae_hip_kernel_info.argtypes = [i, i, i, i, ctypes.c_char_p, sz]
     L.rqae_hip_kernel_info.restype = i
@@ -362,8 +362,10 @@ def subfeatures(codebook: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor
     return out
 
 
-def subfeature_sims(codebook: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor, want_sims: bool = True):
-    """-> (sims [L, K, K] f16 or None, layer_norms [L] fp32); rqae/model.py:158-178, from the Gram matrices in fp64."""
+def subfeature_sims(codebook: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor, want_sims: bool = True,
+                    scale_by_layer_norms: bool = False):
+    """-> (sims [L, K, K] f16 or None, layer_norms [L] fp32); rqae/model.py:158-178, from the Gram matrices in fp64.
+    scale_by_layer_norms: the table as the demo server keeps it (`sims *= layer_norms`, demo/server/server.py:108)."""
     cb, wo, bo = _f32_dev(codebook, "codebook"), _f32_dev(w_out, "w_out"), _f32_dev(b_out, "b_out")
     L, K, c = cb.shape
     d = wo.shape[1]
@@ -377,7 +379,8 @@ def subfeature_sims(codebook: torch.Tensor, w_out: torch.Tensor, b_out: torch.Te
     norms = torch.empty(L, dtype=torch.float32, device=cb.device)
     with torch.cuda.device(cb.device):
         rc = lib().rqae_hip_subfeature_sims(cb.data_ptr(), wo.data_ptr(), bo.data_ptr(), L, K, c, d, scratch.data_ptr(),
-                                            sims.data_ptr() if want_sims else None, norms.data_ptr(), _stream(cb.device))
+                                            sims.data_ptr() if want_sims else None, norms.data_ptr(),
+                                            1 if scale_by_layer_norms else 0, _stream(cb.device))
     _check(rc, "rqae_hip_subfeature_sims")
     return sims, norms
 

@@ -775,8 +775,9 @@ size_t rqae_hip_tables_scratch_bytes(int L, int K, int c)
 }
 
 int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const float *b_out, int L, int K, int c, int d,
-                             void *scratch, void *sims_out, float *layer_norms_out, void *stream)
+                             void *scratch, void *sims_out, float *layer_norms_out, int scale_by_layer_norms, void *stream)
 {
+    const int scaled = scale_by_layer_norms ? 1 : 0;
     if (!codebook || !w_out || !b_out || !scratch) return fail("subfeature_sims: null pointer");
     if (!sims_out && !layer_norms_out) return fail("subfeature_sims: nothing to compute");
     if (!shape_ok(d, c, K, L) || L > 65535) return fail("subfeature_sims: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
@@ -791,7 +792,7 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
     const double *scr = (const double *)scratch;
     if (K < 64) {
         hipLaunchKernelGGL(subfeature_sims_small_kernel, dim3((unsigned)((K * K + 255) / 256), (unsigned)L), dim3(256), 0, s,
-                           codebook, scr, K, c, sims);
+                           codebook, scr, K, c, scaled, sims);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -811,7 +812,7 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, codebook, scr, K, c, TR, PR, ncol, sims);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, codebook, scr, K, c, TR, PR, ncol, scaled, sims);
         return 0;
     };
     switch (MB) {

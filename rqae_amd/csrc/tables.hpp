@@ -103,11 +103,19 @@ subfeatures_kernel(const float *__restrict__ cb, const float *__restrict__ w_out
 // the reference's fp32 product of fp32-rounded subfeatures; tests/ bound the distance to the reference capture by
 // the reference's own rounding (<= 1 fp16 ulp, > 99.9 % identical).  layer_norms[l] = mean_k sqrt(G[k][k]), k < c.
 //
-// scratch, per level (m = c+1): G [m][m] | inv [K] = 1/max(|u_n|, 1e-12) | gv [K][m] = (G v_n) * inv[n], doubles.
+// scratch, per level (m = c+1): G [m][m] | inv [K] = 1/max(|u_n|, 1e-12) | gv [K][m] = (G v_n) * inv[n] | norm, doubles.
 __host__ __device__ inline size_t tables_level_doubles(int K, int c)
 {
     const size_t m = (size_t)c + 1;
-    return m * m + (size_t)K + (size_t)K * m;
+    return m * m + (size_t)K + (size_t)K * m + 1;   // ... | the level's layer norm (as the fp32 value, in a double)
+}
+
+// The table element from its fp64 value: fp16 as RQAE.subfeature_sims holds it, or -- scaled -- what the demo server
+// keeps after `sims *= layer_norms` (demo/server/server.py:108): the fp16 value times the fp32 norm, rounded to fp16.
+__device__ __forceinline__ _Float16 sims_finish(double v, float norm, bool scaled)
+{
+    const _Float16 h = (_Float16)(float)v;
+    return scaled ? (_Float16)((float)h * norm) : h;
 }
 
 // tables_prep_kernel: blockIdx.x = level; blockIdx.y = a chunk of 1024 codebook rows (every chunk's block forms G
@@ -154,10 +162,12 @@ tables_prep_kernel(const float *__restrict__ cb, const float *__restrict__ w_out
         }
     }
     __syncthreads();
-    if (tid == 0 && layer_norms && blockIdx.y == 0) {
+    if (tid == 0 && blockIdx.y == 0) {
         double s = 0.0;
         for (int k = 0; k < c; ++k) s += sqrt(sG[k][k]);
-        layer_norms[l] = (float)(s / c);
+        const float nrm = (float)(s / c);
+        if (layer_norms) layer_norms[l] = nrm;
+        G[m * m + K + (size_t)K * m] = (double)nrm;
     }
     double *inv = G + m * m, *gv = inv + K;
     for (int n = blockIdx.y * 1024 + tid; n < min(K, (int)(blockIdx.y + 1) * 1024); n += 256) {
@@ -186,13 +196,14 @@ tables_prep_kernel(const float *__restrict__ cb, const float *__restrict__ w_out
 
 // One element of the table from the scratch block (the slow path: ragged pieces and tiny codebooks).
 __device__ __forceinline__ _Float16 sims_element(const float *__restrict__ cbl, const double *__restrict__ inv,
-                                                 const double *__restrict__ gv, int c, int row, int col)
+                                                 const double *__restrict__ gv, int c, int row, int col, float norm,
+                                                 bool scaled)
 {
     const int m = c + 1;
     const double iv = inv[col];
     double acc = 0.0;
     for (int a = 0; a < m; ++a) acc = fma(gv[(size_t)row * m + a], (a < c ? (double)cbl[(size_t)col * c + a] : 1.0) * iv, acc);
-    return (_Float16)(float)acc;
+    return sims_finish(acc, norm, scaled);
 }
 
 // subfeature_sims_kernel: a block owns TR rows x up to 256 pieces of one level; a piece is NC consecutive fp16 of
@@ -208,7 +219,7 @@ __device__ __forceinline__ _Float16 sims_element(const float *__restrict__ cbl, 
 template <int MB, int NC>
 __global__ void __launch_bounds__(256)
 subfeature_sims_kernel(const float *__restrict__ cb, const double *__restrict__ scratch, int K, int c, int TR,
-                       int PR, int ncol_lds, _Float16 *__restrict__ out)
+                       int PR, int ncol_lds, int scaled, _Float16 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int l = blockIdx.y, row0 = blockIdx.x * TR, P0 = blockIdx.z * 256, tid = threadIdx.x, m = c + 1;
@@ -225,6 +236,7 @@ subfeature_sims_kernel(const float *__restrict__ cb, const double *__restrict__ 
     float *cbs = reinterpret_cast<float *>(invs + plane);               // [c][plane]
     auto pad = [](int x) { return x + x / NC; };
     const double *G = scratch + (size_t)l * tables_level_doubles(K, c), *inv = G + m * m, *gv = inv + K;
+    const float norm = scaled ? (float)gv[(size_t)K * m] : 1.0f;
     const float *cbl = cb + (size_t)l * K * c;
     for (int e = tid - MB; e < nrow * MB; e += 256) {
         const int r = e < 0 ? -1 : e / MB, a = e < 0 ? e + MB : e % MB;
@@ -266,7 +278,7 @@ subfeature_sims_kernel(const float *__restrict__ cb, const double *__restrict__ 
                 typedef _Float16 hvec __attribute__((ext_vector_type(NC)));
                 hvec h;
 #pragma unroll
-                for (int j = 0; j < NC; ++j) h[j] = (_Float16)(float)acc[j];
+                for (int j = 0; j < NC; ++j) h[j] = sims_finish(acc[j], norm, scaled != 0);
                 *reinterpret_cast<hvec *>(dst + (size_t)i * K) = h;
             }
         }
@@ -280,7 +292,7 @@ subfeature_sims_kernel(const float *__restrict__ cb, const double *__restrict__ 
                 const double x = a < c ? (double)(in_lds ? cbs[a * plane + pad(col - c_lo)] : cbl[(size_t)col * c + a]) : 1.0;
                 acc = fma(gvs[i * MB + a], x * iv, acc);
             }
-            return (_Float16)(float)acc;
+            return sims_finish(acc, norm, scaled != 0);
         };
         for (int t = tid; t < nrow * NC; t += 256) {
             const int i = t / NC, j = t % NC, r = row0 + i;
@@ -298,13 +310,14 @@ subfeature_sims_kernel(const float *__restrict__ cb, const double *__restrict__ 
 // K < 64: one lane per element.
 __global__ void __launch_bounds__(256)
 subfeature_sims_small_kernel(const float *__restrict__ cb, const double *__restrict__ scratch, int K, int c,
-                             _Float16 *__restrict__ out)
+                             int scaled, _Float16 *__restrict__ out)
 {
     const int l = blockIdx.y, m = c + 1;
     const double *G = scratch + (size_t)l * tables_level_doubles(K, c), *inv = G + m * m, *gv = inv + K;
+    const float norm = scaled ? (float)gv[(size_t)K * m] : 1.0f;
     const float *cbl = cb + (size_t)l * K * c;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < K * K; e += gridDim.x * 256)
-        out[(size_t)l * K * K + e] = sims_element(cbl, inv, gv, c, e / K, e % K);
+        out[(size_t)l * K * K + e] = sims_element(cbl, inv, gv, c, e / K, e % K, norm, scaled != 0);
 }
 
 }  // namespace

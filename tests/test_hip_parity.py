@@ -722,3 +722,19 @@ def test_c_abi_from_a_c_program(tmp_path):
     q_o, idx_o = oracle.forward(x, w)
     assert np.array_equal(idx, idx_o) and np.array_equal(q, q_o)
     assert np.array_equal(dec, oracle.decode(idx_o, w))
+
+
+def test_subfeature_sims_scaled_as_the_server_keeps_them():
+    """scale_by_layer_norms = the table after the demo server's `sims *= model.layer_norms[:, None, None]`
+    (demo/server/server.py:101-112): the fp16 cosine times the fp32 norm, rounded to fp16 -- in the same pass."""
+    for cfgname, L in [("P", 3), ("C1", 2)]:
+        cfg = dict(synth.CONFIGS[cfgname]); cfg["num_quantizers"] = L
+        w = synth.weights(55, cfg["dim"], cfg["codebook_dim"], L, cfg["codebook_size"])
+        m = make_model(cfg, w)
+        args = m._table_inputs()
+        plain, norms = _native.subfeature_sims(*args)
+        scaled, norms2 = _native.subfeature_sims(*args, scale_by_layer_norms=True)
+        torch.cuda.synchronize()
+        want = plain.clone()
+        want *= norms.unsqueeze(-1).unsqueeze(-1)          # the server's line, torch's own fp16 *= fp32 semantics
+        assert torch.equal(norms, norms2) and torch.equal(scaled, want)

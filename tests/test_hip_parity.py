@@ -738,3 +738,46 @@ def test_subfeature_sims_scaled_as_the_server_keeps_them():
         want = plain.clone()
         want *= norms.unsqueeze(-1).unsqueeze(-1)          # the server's line, torch's own fp16 *= fp32 semantics
         assert torch.equal(norms, norms2) and torch.equal(scaled, want)
+
+
+def test_fused_hook_with_the_transformers_rmsnorm_module():
+    """The module the real caller hands over (rqae/llm.py:65-73 reads `llm.model.model.norm` of a HF Gemma-2):
+    transformers' own Gemma2RMSNorm is recognised and its weight / eps mean what the kernels assume."""
+    hf = pytest.importorskip("transformers.models.gemma2.modeling_gemma2")
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    d = cfg["dim"]
+    norm = hf.Gemma2RMSNorm(d, eps=1e-6).to(DEV)
+    rng = np.random.Generator(np.random.PCG64(8))
+    with torch.no_grad():
+        norm.weight.copy_(torch.from_numpy((0.1 * rng.standard_normal(d)).astype(np.float32)))
+
+    class LLM:                                           # rqae/llm.py:Gemma2, the parts the hook touches
+        def __init__(self):
+            inner = torch.nn.Module(); inner.norm = norm
+            outer = torch.nn.Module(); outer.model = inner
+            self.model = outer
+
+        def norm(self, hs):
+            return self.model.model.norm(hs)
+
+        def denorm(self, q, orig):
+            q = q / (1.0 + self.model.model.norm.weight.float())
+            return q.float() / torch.rsqrt(orig.float().pow(2).mean(-1, keepdim=True) + 1e-6)
+
+    llm = LLM()
+    hs0 = (torch.from_numpy(synth.activations(78, 2 * 50, d)) * 3.0).to(torch.float16).view(2, 50, d).to(DEV)
+    out = {}
+    for fused in (True, False):
+        hs, st = hs0.clone(), {}
+        with torch.inference_mode():
+            m.hook(llm=llm, store=lambda k, v: st.update({k: v}), fused=fused)(None, None, (hs,))
+        torch.cuda.synchronize()
+        out[fused] = (hs, st)
+    (hs_f, st_f), (hs_g, st_g) = out[True], out[False]
+    assert rel_err(st_f["normed"].cpu().numpy(), st_g["normed"].cpu().numpy()) < 1e-6    # HF module == kernel's norm
+    ok = (st_f["indices"] == st_g["indices"]).all(-1)
+    assert ok.float().mean().item() >= 0.98
+    assert rel_err(st_f["new"][ok].cpu().numpy(), st_g["new"][ok].cpu().numpy()) < 1e-5
+    assert torch.equal(hs_f[:, 0], hs0[:, 0]) and not torch.equal(hs_f[:, 1:], hs0[:, 1:])

@@ -34,21 +34,71 @@ rqae_quantize_kernel(const QuantParams p)
     for (int it = 0; it < p.iters; ++it) {
         const long long tokw = (((long long)blockIdx.x * p.iters + it) * 4 + wave) * TQ;
         if (nchunk == 1 && tokw >= p.n) break;                // wave-uniform; (a chunked codebook has barriers below: every wave stays)
-        float q[TQ][C], xn[TQ][C], best[TQ];
+        float best[TQ];
         int bidx[TQ];
 #pragma unroll
-        for (int tq = 0; tq < TQ; ++tq) {
-            const long long tok = tokw + tq;
+        for (int tq = 0; tq < TQ; ++tq) { best[tq] = -INFINITY; bidx[tq] = 0; }
+        // c <= 8: lane (token, j) = (lane / 8, lane % 8) divides its own component once (the encode kernel's quantise
+        // phase), the unit vectors reach every lane as SGPR pairs and the scan is packed over the two token pairs.
+        // c > 8: every lane normalises all four tokens itself and scans with plain fmas.
+        float xn[C > 8 ? TQ : 1][C];
+        f2 xs2[C > 8 ? 1 : TQ / 2][C];
+        if constexpr (C <= 8) {
+            const int tq_l = lane >> 3, jj = lane & 7;
+            const long long tok_own = tokw + (tq_l < TQ ? tq_l : 0);
+            const bool mine = tq_l < TQ && tok_own < p.n;
+            float qk[C];
 #pragma unroll
-            for (int j = 0; j < C; ++j) q[tq][j] = (j < cp && tok < p.n) ? p.p[tok * cp + j] : 0.0f;
-            const float nrm = aten_norm2<C>(q[tq], cp);
+            for (int k = 0; k < C; ++k) qk[k] = (k < cp && mine) ? p.p[tok_own * cp + k] : 0.0f;
+            const float nrm = aten_norm2<C>(qk, cp);
+            const float q_own = (jj < cp && mine) ? p.p[tok_own * cp + jj] : 0.0f;
+            const float xn_own = q_own / nrm;
 #pragma unroll
-            for (int j = 0; j < C; ++j) xn[tq][j] = q[tq][j] / nrm;
-            best[tq] = -INFINITY;
-            bidx[tq] = 0;
+            for (int pr = 0; pr < TQ / 2; ++pr)
+#pragma unroll
+                for (int k = 0; k < C; ++k)   // components beyond c are exact zeros: their fmas add +0
+                    xs2[pr][k] = k < cp ? (f2){lane_bcast(xn_own, 16 * pr + k), lane_bcast(xn_own, 16 * pr + 8 + k)} : splat2(0.0f);
+        } else {
+#pragma unroll
+            for (int tq = 0; tq < TQ; ++tq) {
+                const long long tok = tokw + tq;
+                float q[C];
+#pragma unroll
+                for (int j = 0; j < C; ++j) q[j] = (j < cp && tok < p.n) ? p.p[tok * cp + j] : 0.0f;
+                const float nrm = aten_norm2<C>(q, cp);
+#pragma unroll
+                for (int j = 0; j < C; ++j) xn[tq][j] = q[j] / nrm;
+            }
         }
+        auto scan = [&](int rows, int row_base) {
+            if constexpr (C <= 8) {
+                for (int r0 = 0; r0 < rows; r0 += 64) {
+                    const int row = r0 + lane;
+                    const bool in = row < rows;
+                    float cbv[C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const float v = smem[(in ? row : 0) * cp + (k < cp ? k : cp - 1)];
+                        cbv[k] = k < cp ? v : 0.0f;
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < TQ / 2; ++pr) {
+                        f2 sv = splat2(0.0f);
+#pragma unroll
+                        for (int k = 0; k < C; ++k) sv = fma2(xs2[pr][k], splat2(cbv[k]), sv);
+                        const bool u0 = in && sv.x > best[2 * pr], u1 = in && sv.y > best[2 * pr + 1];   // selects, no branches
+                        best[2 * pr] = u0 ? sv.x : best[2 * pr];
+                        bidx[2 * pr] = u0 ? row_base + row : bidx[2 * pr];
+                        best[2 * pr + 1] = u1 ? sv.y : best[2 * pr + 1];
+                        bidx[2 * pr + 1] = u1 ? row_base + row : bidx[2 * pr + 1];
+                    }
+                }
+            } else {
+                scan_rows<C, TQ>(xn, smem, rows, row_base, cp, lane, best, bidx);
+            }
+        };
         if (nchunk == 1) {
-            scan_rows<C, TQ>(xn, smem, p.K, 0, cp, lane, best, bidx);
+            scan(p.K, 0);
         } else {
             for (int ch = 0; ch < nchunk; ++ch) {             // iters == 1 here: every wave of the block takes part
                 const int row_base = ch * p.kch;
@@ -56,7 +106,7 @@ rqae_quantize_kernel(const QuantParams p)
                 if (ch > 0) __syncthreads();
                 stage_floats(smem, p.cb + (size_t)row_base * cp, rows * cp);
                 __syncthreads();
-                scan_rows<C, TQ>(xn, smem, rows, row_base, cp, lane, best, bidx);
+                scan(rows, row_base);
             }
         }
 #pragma unroll

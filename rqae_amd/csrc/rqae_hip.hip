@@ -588,6 +588,7 @@ int rqae_hip_quantize(const float *pin, int64_t n, int c, int K, const float *co
         return 0;
     };
     if (c <= 4) return go(rqae_quantize_kernel<4>);
+    if (c == 5) return go(rqae_quantize_kernel<5>);
     if (c <= 8) return go(rqae_quantize_kernel<8>);
     return go(rqae_quantize_kernel<16>);
 }

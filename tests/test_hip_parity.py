@@ -781,3 +781,30 @@ def test_fused_hook_with_the_transformers_rmsnorm_module():
     assert ok.float().mean().item() >= 0.98
     assert rel_err(st_f["new"][ok].cpu().numpy(), st_g["new"][ok].cpu().numpy()) < 1e-5
     assert torch.equal(hs_f[:, 0], hs0[:, 0]) and not torch.equal(hs_f[:, 1:], hs0[:, 1:])
+
+
+def test_tables_at_the_pretrained_shape():
+    """The full (1024, 625, 625) subfeature_sims table of the pretrained shape (d 2304, c 4, 1024 levels): properties
+    that need no oracle -- unit diagonal, symmetry to an fp16 ulp, range -- plus three levels against the oracle's
+    double-precision restatement, and layer_norms of every level."""
+    cfg = dict(dim=2304, codebook_dim=4, codebook_size=5, num_quantizers=1024)
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    sims, norms = m.subfeature_sims, m.layer_norms
+    torch.cuda.synchronize()
+    L, K = 1024, 625
+    assert sims.shape == (L, K, K) and sims.dtype == torch.float16
+    f = sims.float()
+    assert bool((torch.diagonal(f, dim1=1, dim2=2) == 1.0).all())
+    assert float(f.abs().max()) <= 1.0
+    asym = (f - f.transpose(1, 2)).abs()
+    assert bool((asym <= 2.0 ** -10 * f.abs().clamp_min(2.0 ** -14)).all())       # at most one fp16 ulp apart
+    assert float((asym == 0).float().mean()) > 0.9999
+    for l in (0, 511, 1023):
+        exact = oracle.subfeature_sims(w, levels=[l])[0]
+        got = sims[l].cpu().numpy()
+        r16 = exact.astype(np.float16)
+        near = 0.5 * np.spacing(np.abs(r16)).astype(np.float64) - np.abs(exact - r16.astype(np.float64)) < 5e-8
+        same = got.view(np.uint16) == r16.view(np.uint16)
+        assert (same | near).all() and same.mean() > 0.9995
+    assert np.array_equal(norms.cpu().numpy(), oracle.layer_norms(w).astype(np.float32))

@@ -808,3 +808,26 @@ def test_tables_at_the_pretrained_shape():
         same = got.view(np.uint16) == r16.view(np.uint16)
         assert (same | near).all() and same.mean() > 0.9995
     assert np.array_equal(norms.cpu().numpy(), oracle.layer_norms(w).astype(np.float32))
+
+
+def test_pretrained_depth_end_to_end():
+    """The shape of the published checkpoint (d 2304, c 4, K 625, 1024 levels; rqae/model.py:18-24): forward, the
+    codes-only kernel, decode (all levels and a subset) on 200 tokens bit for bit against the oracle."""
+    cfg = dict(dim=2304, codebook_dim=4, codebook_size=5, num_quantizers=1024)
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    n = 200
+    x = synth.activations(4242, n, cfg["dim"])
+    q, idx = run_forward(m, x)
+    q_o, idx_o = oracle.forward(x, w)
+    assert np.array_equal(idx, idx_o) and np.array_equal(q, q_o)
+    with torch.inference_mode():
+        xt = torch.from_numpy(x).to(DEV).view(1, n, -1)
+        it = torch.from_numpy(idx).to(DEV).view(1, n, -1)
+        codes = m.encode(xt)
+        dec = m.decode(it)
+        dec_sub = m.decode(it.to(torch.int32), layers=[0, 5, 700, 1023])
+    assert np.array_equal(codes[0].cpu().numpy(), idx_o)
+    assert np.array_equal(dec[0].cpu().numpy(), oracle.decode(idx_o, w))
+    assert np.array_equal(dec_sub[0].cpu().numpy(), oracle.decode(idx_o, w, layers=[0, 5, 700, 1023]))
+    assert len(np.unique(idx)) > 300                      # deep levels still spread over the codebook

@@ -522,7 +522,17 @@ template <int P, int C>
 int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
 {
 #if defined(RQAE_TU_MAIN) && !defined(RQAE_TIMELINE)
-    const int NHsel = (!p.q_out && !use_mfma && !p.norm_w) ? 3 : 2;   // codes only: 12 waves x 8 tokens
+    // codes only: 12 waves x 8 tokens.  Small batches with the reconstruction (the hook is called with 4 x 128
+    // tokens, scripts/1_create_activations.py:143-186): 4 waves x 8 tokens, so that twice as many CUs take part
+    // and a level's sweeps run one wave per SIMD.
+    static int n_cu_small = 0;
+    if (n_cu_small == 0) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu_small, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const bool plain = !use_mfma && !p.norm_w;
+    const int NHsel = (plain && !p.q_out) ? 3 : (plain && p.q_out && p.n_tokens <= 8LL * n_cu_small) ? 1 : 2;
 #else
     const int NHsel = 2;
 #endif
@@ -598,6 +608,9 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
     }
 #endif
 #if defined(RQAE_TU_MAIN) || defined(RQAE_SINGLE_TU)
+#if defined(RQAE_TU_MAIN) && !defined(RQAE_TIMELINE)
+    if (p.q_out && NHsel == 1) return go(rqae_encode_lds_kernel<P, C, true, false, false, 1>);
+#endif
     if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, false>);
 #if defined(RQAE_TU_MAIN) && !defined(RQAE_TIMELINE)
     return go(rqae_encode_lds_kernel<P, C, false, false, false, 3>);

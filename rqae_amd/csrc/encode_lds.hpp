@@ -532,7 +532,7 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
         HIP_TRY(hipDeviceGetAttribute(&n_cu_small, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const bool plain = !use_mfma && !p.norm_w;
-    const int NHsel = (plain && !p.q_out) ? 3 : (plain && p.q_out && p.n_tokens <= 8LL * n_cu_small) ? 1 : 2;
+    const int NHsel = (plain && !p.q_out) ? 3 : (!use_mfma && p.q_out && p.n_tokens <= 8LL * n_cu_small) ? 1 : 2;
 #else
     const int NHsel = 2;
 #endif
@@ -595,6 +595,9 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
     if (p.norm_w) {
         if (!p.q_out) return fail("encode_gemma: the reconstruction output is required");
         if (use_mfma) return fail("encode_gemma: no MFMA arm");
+#if defined(RQAE_TU_MAIN) && !defined(RQAE_TIMELINE)
+        if (NHsel == 1) return go(rqae_encode_lds_kernel<P, C, true, false, true, 1>);
+#endif
 #if defined(RQAE_TU_MAIN) || defined(RQAE_SINGLE_TU)
         return go(rqae_encode_lds_kernel<P, C, true, false, true>);
 #else

@@ -14,7 +14,7 @@ import subprocess
 TL_SO = os.path.join(ROOT, "tools", "_build", "librqae_hip_tl.so")
 SRC = os.path.join(ROOT, "rqae_amd", "csrc", "rqae_hip.hip")
 if not os.path.exists(TL_SO) or any(os.path.getmtime(TL_SO) < os.path.getmtime(os.path.join(os.path.dirname(SRC), f))
-                                    for f in ("rqae_hip.hip", "encode_lds.hpp", "rqae_common.hpp", "decode.hpp", "hook.hpp", "intensity.hpp")):
+                                    for f in ("rqae_hip.hip", "encode_lds.hpp", "rqae_common.hpp", "decode.hpp", "hook.hpp", "intensity.hpp", "tables.hpp")):
     os.makedirs(os.path.dirname(TL_SO), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
                     "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-sched-strategy=max-ilp",

@@ -11,11 +11,13 @@ namespace {
 // NH: token halves of 8 tokens (4 waves each).  2 with the reconstruction (its registers allow 2 waves per SIMD);
 // the codes-only kernel of d = 2304 runs 3 (12 waves, 24 tokens per workgroup, 168 VGPRs): the latency-bound
 // quantise phase then serves 24 tokens per level instead of 16 and the sweeps issue at the 3-wave rate.
-template <int P, int C, bool RECON, bool MFMA, bool NORM = false, int NH = 2>
+// TPWT: tokens per wave, 8 or 4 (4 only for the smallest batches: one token group per wave, 4 tokens per workgroup).
+template <int P, int C, bool RECON, bool MFMA, bool NORM = false, int NH = 2, int TPWT = 8>
 __global__ void __launch_bounds__(256 * NH, NH)
 rqae_encode_lds_kernel(const EncParams p)
 {
-    constexpr int TPW = 8, NW = 4 * NH, TG = TPW * NH, TQ = 2, JW = 8, NG = 2, NPAIR = 4;
+    constexpr int TPW = TPWT, NW = 4 * NH, TG = TPW * NH, TQ = 2, JW = 8, NG = TPW / 4, NPAIR = TPW / 2;
+    static_assert(TPW == 8 || (TPW == 4 && !NORM && !MFMA), "token groups of four; the norm prologue is written for 8");
 #ifdef RQAE_ABLATE_BUILD   // timing experiments only (tools/timeline.py): RQAE_HIP_ABLATE bits skip parts of the kernel
     const int ABLATE = p.ablate;
 #else
@@ -63,7 +65,7 @@ rqae_encode_lds_kernel(const EncParams p)
     // quantise-phase role of this lane: lanes 0..7 -> token 2*wave, lanes 8..15 -> token 2*wave+1
     const int tq = lane / JW, jj = lane % JW;
     const int tl_q = wave * TQ + (tq < TQ ? tq : 0);
-    const bool act = tq < TQ && jj < C;
+    const bool act = tq < TQ && jj < C && tl_q < TG;   // (with 4 tokens per workgroup only waves 0 and 1 quantise)
 
     const unsigned wts_addr = lds_addr_of(wts);
     // The record of pass pl goes to `wts` in 1-KiB pieces; every wave owns a contiguous run of them and issues
@@ -533,10 +535,11 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
     }
     const bool plain = !use_mfma && !p.norm_w;
     const int NHsel = (plain && !p.q_out) ? 3 : (!use_mfma && p.q_out && p.n_tokens <= 8LL * n_cu_small) ? 1 : 2;
+    const int TPWsel = (NHsel == 1 && plain && p.n_tokens <= 4LL * n_cu_small) ? 4 : 8;
 #else
-    const int NHsel = 2;
+    const int NHsel = 2, TPWsel = 8;
 #endif
-    const int TG = 8 * NHsel;
+    const int TG = TPWsel * NHsel;
     EncParams q = p;
     const size_t fixed = sizeof(float) * ((size_t)NSLICE * rec_quads(P, C) * 256 + NSLICE * TG * C + ((TG * C + 3) & ~3));
     const size_t cb_budget = 160 * 1024 - fixed - 1024;
@@ -612,6 +615,7 @@ int launch_encode_lds(const EncParams &p, hipStream_t stream, bool use_mfma)
 #endif
 #if defined(RQAE_TU_MAIN) || defined(RQAE_SINGLE_TU)
 #if defined(RQAE_TU_MAIN) && !defined(RQAE_TIMELINE)
+    if (p.q_out && NHsel == 1 && TPWsel == 4) return go(rqae_encode_lds_kernel<P, C, true, false, false, 1, 4>);
     if (p.q_out && NHsel == 1) return go(rqae_encode_lds_kernel<P, C, true, false, false, 1>);
 #endif
     if (p.q_out) return go(rqae_encode_lds_kernel<P, C, true, false>);

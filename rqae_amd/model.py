@@ -445,7 +445,11 @@ class RQAE(nn.Module):
                 return generic_hook(module, input, output)   # same values, torch ops around forward()
             if store is not None:
                 store("original", hs_llm.float())
+            # (small batches run on 4-token workgroups, which only the plain encode kernel has: below 8 tokens per
+            #  CU the norm as its own kernel + forward is the faster pair -- 3.06 vs 3.63 ms at 4 x 128 tokens, 1024 levels)
+            n_tok = hs_llm.shape[0] * hs_llm.shape[1]
             fold = (store is None and hs_llm.shape[-1] == self._dim and self.quantization_method in _FSQ_METHODS
+                    and n_tok > 8 * torch.cuda.get_device_properties(hs_llm.device).multi_processor_count
                     and _native.encode_gemma_supported(self._dims()))
             if fold:
                 # nobody asked for `normed`: the norm runs inside the encode kernel's load (same bits)

@@ -462,7 +462,7 @@ rqae_encode_lds_kernel(const EncParams p)
         TL_STAMP();
         __syncthreads();
         TL_STAMP();
-        if (!(ABLATE & 1)) dma_begin(l + 1);
+        if (!(ABLATE & 1) && (RECON || l + 1 < p.levels)) dma_begin(l + 1);   // (codes only: the last record is never applied)
         if (!(ABLATE & 2)) quantise(l, bin_own);
         else dma_flush();
         TL_STAMP();
@@ -493,8 +493,10 @@ rqae_encode_lds_kernel(const EncParams p)
         restage(l + 1);
         slot(l + 1, bin_own);
     }
-    if (p.levels > 1) pass_out(F{}, T{});                 // apply the last level
-    else pass_out(T{}, T{});
+    if constexpr (RECON) {                                // apply the last level (codes only: nothing left to do)
+        if (p.levels > 1) pass_out(F{}, T{});
+        else pass_out(T{}, T{});
+    }
     TL_STAMP();
 #ifdef RQAE_TIMELINE
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory");

@@ -30,6 +30,8 @@ WORKLOAD = "C2: Gemma-2-2B layer-12 residual stream (synthetic), d=2304, K=1024,
 D, C, K, L = 2304, 5, 1024, 8
 BYTES_PER_TOKEN = D * 2 + D * 4 + L * 8                      # bf16 x in, fp32 recon + int64 codes out = 13888
 FLOPS_PER_TOKEN = L * (2 * D * C + 2 * C * K + 2 * C * D + 2 * D)  # 487424
+# codes only: no `out += y`, and the last level needs neither lin_out nor `r -= y`          = 443648
+FLOPS_PER_TOKEN_CODES = L * (2 * D * C + 2 * C * K) + (L - 1) * (2 * C * D + D)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector) peak
 
@@ -134,7 +136,8 @@ def main():
         value = sharding.aggregate_throughput(args.tokens, world, args.steps, elapsed)
         bytes_tok = (D * 2 + L * 8) if args.codes_only else BYTES_PER_TOKEN
         tok_per_s_kernel = args.tokens / (kern_ms * 1e-3)
-        tflops = tok_per_s_kernel * FLOPS_PER_TOKEN / 1e12
+        flops_tok = FLOPS_PER_TOKEN_CODES if args.codes_only else FLOPS_PER_TOKEN
+        tflops = tok_per_s_kernel * flops_tok / 1e12
         gbs = tok_per_s_kernel * bytes_tok / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
@@ -156,7 +159,7 @@ def main():
                        "kernel": _native.kernel_info(D, C, K, L)},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / PEAK_F32_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "flops_per_token": FLOPS_PER_TOKEN,
+                         "kernel_ms": kern_ms, "flops_per_token": flops_tok,
                          "hbm_achieved_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "bytes_per_token": bytes_tok},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQAE_HIP_ABI_VERSION 1
+#define RQAE_HIP_ABI_VERSION 2
 
 /* element type of the activation matrix x */
 enum { RQAE_X_F32 = 0, RQAE_X_BF16 = 1, RQAE_X_F16 = 2 };
@@ -167,6 +167,31 @@ size_t rqae_hip_tables_scratch_bytes(int L, int K, int c);
 int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const float *b_out, int L, int K, int c, int d,
                              void *scratch, void *sims_out, float *layer_norms_out, int scale_by_layer_norms,
                              void *stream);
+
+/*
+ * The matrix-core arm of RQAE.forward ("gram arm", csrc/gram.hip).  Same inputs and outputs as
+ * rqae_hip_encode (rqae/model.py:199-230), different arithmetic: lin_in of every level as ONE [tokens,d] x [d,L*c]
+ * product, the level chain in c-space on precomputed c x c Gram blocks W_in[l] W_out[m], the
+ * reconstruction as the decode sum (rqae/model.py:236-248) -- all three products on v_mfma_f32_16x16x32_bf16 with fp32
+ * operands cut into three exact bf16 pieces.  Results carry fp32-level rounding but are not the bits of
+ * rqae_hip_encode: parity is SURVEY 8(c) Tier 2 (codes identical wherever the top-1/top-2 cosine margin is
+ * >= 1e-5; q_out within 1e-5 relative).  Exact duplicate codebook rows still resolve to the lowest index.
+ *   rqae_hip_gram_supported      1 if the shape is served (d % 128 == 0, c <= 5, L <= 64, one codebook shared by all
+ *                                levels and small enough to stay in LDS), else 0 -> use rqae_hip_encode
+ *   rqae_hip_gram_packed_bytes   size of the arm's own parameter block (0 = unsupported)
+ *   rqae_hip_gram_pack           builds it from the stacked fp32 tensors (same arguments as rqae_hip_pack)
+ *   rqae_hip_gram_workspace_bytes scratch the caller lends to one rqae_hip_encode_gram call: the projections
+ *                                [groups][tokens][16] fp32 and the reconstruction operand rows [k-steps][tokens][32]
+ *                                bf16 of at most 131072 tokens at a time (longer batches run in passes)
+ *   rqae_hip_encode_gram         x, q_out (or NULL), workspace 16-byte aligned; indices int64 [n_tokens][levels]
+ */
+int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared);
+size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared);
+int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
+                       const float *codebook, const float *w_out, const float *b_out, int codebook_shared, void *stream);
+size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels);
+int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
+                         int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream);
 
 /* Human-readable name of the encode kernel variant chosen for a shape. */
 int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);

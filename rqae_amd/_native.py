@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "librqae_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 IDX_I64, IDX_I32, IDX_U16 = 0, 1, 2
 
@@ -39,6 +39,11 @@ SYMBOLS = (
     "rqae_hip_tables_scratch_bytes",
     "rqae_hip_subfeature_sims",
     "rqae_hip_kernel_info",
+    "rqae_hip_gram_supported",
+    "rqae_hip_gram_packed_bytes",
+    "rqae_hip_gram_pack",
+    "rqae_hip_gram_workspace_bytes",
+    "rqae_hip_encode_gram",
 )
 
 _lib = None
@@ -96,6 +101,16 @@ def lib():
     L.rqae_hip_subfeature_sims.restype = i
     L.rqae_hip_kernel_info.argtypes = [i, i, i, i, ctypes.c_char_p, sz]
     L.rqae_hip_kernel_info.restype = i
+    L.rqae_hip_gram_supported.argtypes = [i, i, i, i, i]
+    L.rqae_hip_gram_supported.restype = i
+    L.rqae_hip_gram_packed_bytes.argtypes = [i, i, i, i, i]
+    L.rqae_hip_gram_packed_bytes.restype = sz
+    L.rqae_hip_gram_pack.argtypes = [vp, i, i, i, i, vp, vp, vp, vp, vp, i, vp]
+    L.rqae_hip_gram_pack.restype = i
+    L.rqae_hip_gram_workspace_bytes.argtypes = [i, i, i, i, i64, i]
+    L.rqae_hip_gram_workspace_bytes.restype = sz
+    L.rqae_hip_encode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, vp]
+    L.rqae_hip_encode_gram.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"librqae_hip.so ABI {L.rqae_hip_abi_version()} != expected {ABI_VERSION}; rebuild")
@@ -166,6 +181,63 @@ def encode(packed, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True
                                    n, levels, q.data_ptr() if want_recon else None, idx.data_ptr(),
                                    _stream(x2d.device))
     _check(rc, "rqae_hip_encode")
+    return q, idx
+
+
+# ---- the matrix-core arm (csrc/gram.hip; include/rqae_hip.h "gram arm") -------------------------------------------
+
+def gram_supported(dims, codebook_shared: bool) -> bool:
+    d, c, K, L_ = dims
+    return bool(lib().rqae_hip_gram_supported(d, c, K, L_, int(bool(codebook_shared))))
+
+
+def gram_pack(w_in, b_in, codebook, w_out, b_out, codebook_shared: bool) -> torch.Tensor:
+    """Stacked fp32 parameters -> the gram arm's own device block (bf16 operand images, Gram blocks)."""
+    L_, c, d = w_in.shape
+    K = codebook.shape[1]
+    for n, t in (("w_in", w_in), ("b_in", b_in), ("codebook", codebook), ("w_out", w_out), ("b_out", b_out)):
+        _require_cuda(t, n)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"gram_pack: {n} must be contiguous float32")
+    nbytes = int(lib().rqae_hip_gram_packed_bytes(d, c, K, L_, int(bool(codebook_shared))))
+    if nbytes == 0:
+        _check(1, "rqae_hip_gram_packed_bytes")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w_in.device)
+    with torch.cuda.device(w_in.device):
+        rc = lib().rqae_hip_gram_pack(out.data_ptr(), d, c, K, L_, w_in.data_ptr(), b_in.data_ptr(),
+                                      codebook.data_ptr(), w_out.data_ptr(), b_out.data_ptr(),
+                                      int(bool(codebook_shared)), _stream(w_in.device))
+    _check(rc, "rqae_hip_gram_pack")
+    return out
+
+
+def gram_workspace_bytes(dims, n_tokens: int, levels: int) -> int:
+    d, c, K, L_ = dims
+    return int(lib().rqae_hip_gram_workspace_bytes(d, c, K, L_, n_tokens, levels))
+
+
+def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels: int, want_recon: bool = True,
+                workspace: torch.Tensor | None = None):
+    """x2d [N,d] {f32,bf16,f16} -> (q_out [N,d] f32 | None, indices [N,levels] i64) on the matrix-core arm."""
+    d, c, K, L_ = dims
+    _require_cuda(x2d, "x")
+    if x2d.dtype not in _X_DTYPES:
+        raise RuntimeError(f"encode_gram: unsupported input dtype {x2d.dtype}")
+    if x2d.dim() != 2 or x2d.shape[1] != d or not x2d.is_contiguous():
+        raise RuntimeError("encode_gram: x must be contiguous [N, d]")
+    n = x2d.shape[0]
+    q = torch.empty((n, d), dtype=torch.float32, device=x2d.device) if want_recon else None
+    idx = torch.empty((n, levels), dtype=torch.int64, device=x2d.device)
+    if n == 0:
+        return q, idx
+    need = gram_workspace_bytes(dims, n, levels)
+    if workspace is None or workspace.numel() * workspace.element_size() < need or workspace.device != x2d.device:
+        workspace = torch.empty(need, dtype=torch.uint8, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        rc = lib().rqae_hip_encode_gram(gpacked.data_ptr(), d, c, K, L_, int(bool(codebook_shared)), x2d.data_ptr(),
+                                        _X_DTYPES[x2d.dtype], n, levels, q.data_ptr() if want_recon else None,
+                                        idx.data_ptr(), workspace.data_ptr(), _stream(x2d.device))
+    _check(rc, "rqae_hip_encode_gram")
     return q, idx
 
 

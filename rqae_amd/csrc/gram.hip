@@ -1,0 +1,1075 @@
+// gram.hip -- the matrix-core arm of RQAE.forward for gfx950 ("gram arm").
+//
+// rqae/model.py:199-230 runs, per level l,  q = lin_in_l(r); idx = argmax cos(q, codebook_l);
+// cv = q + (codebook_l[idx] - q); y = lin_out_l(cv); r -= y; out += y.  lin_in is linear in r, so
+//     q_l = W_in[l] x + b_in[l] - sum_{m<l} ( (W_in[l] W_out[m]) cv_m + W_in[l] b_out[m] )
+// ("all-levels-at-once"): the d-long contractions of every level become ONE dense
+// [tokens, d] x [d, L*c] product, the level chain runs in c-space on c x c Gram blocks, and the
+// reconstruction is the decode sum  out = sum_l (W_out[l] cv_l + b_out[l])  -- a second dense product.
+// The residual is never formed.  The three products run on v_mfma_f32_16x16x32_bf16 with every fp32
+// operand cut into three bf16 pieces (hi + mid + lo == the fp32 value exactly; a bf16 x bf16 product is
+// exact in fp32; fp32 accumulation), so the results carry fp32-level rounding only.  They are NOT the
+// bits of the canonical order: this arm is held to SURVEY 8(c)'s Tier-2 policy
+// (codes identical wherever the top-1/top-2 margin is >= 1e-5, reconstruction within 1e-5 relative),
+// the exact arm (rqae_hip_encode) stays bit-exact.
+//
+//   gram_project_kernel      P[tok][l*c+j] = sum_e x[tok][e] W_in[l][j][e]                (rqae/model.py:211, all l)
+//   gram_levels_kernel       the level chain in c-space + cosine argmax on MFMA           (rqae/model.py:187-224)
+//   gram_reconstruct_kernel  out[tok][e] = sum_l W_out[l][e][:] cv_l + b_out[l][e]        (rqae/model.py:221,224)
+//
+// Translation unit of librqae_hip.so (built by __graft_entry__.py); C ABI at the bottom, declared in
+// include/rqae_hip.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "../../include/rqae_hip.h"
+
+extern __attribute__((visibility("hidden"))) __thread char rqae_g_err[512];   // __thread, not thread_local: no TLS init wrapper (a hidden weak _ZTH call crashes)
+
+namespace {
+
+int gfail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int gfail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(rqae_g_err, sizeof(rqae_g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+#define G_TRY(expr)                                                                      \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return gfail("%s: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// compile-time loop: the body is instantiated once per index (hipcc refuses to unroll the level loop by pragma)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int GRAM_MAGIC = 0x4752414d;  // "GRAM"
+constexpr int GRAM_MAX_L = 64;
+constexpr int GRAM_MAX_C = 5;           // instantiated: CP = 4, 5
+
+// ------------------------------------------------------------------------------------------------ geometry
+// CP   padded codebook_dim the kernels are instantiated for (c <= CP, padding is zero weights)
+// GL   levels per level group (the c-space state of one group lives in registers)
+// GP   outputs per level group in P, padded to whole 16-wide MFMA tiles
+// GS   reconstruction slots per level group, padded to whole 32-deep k-steps (6 bf16 x bf16 terms per component)
+// NKC  k-steps of the cosine contraction (6*CP slots)
+struct Geom {
+    int d, c, K, L, CP, GL, GP, GS, NLG, NOG, KSA, NKC, KT, KTP, NET, NKSC, GB, shared_cb;
+};
+
+__host__ __device__ inline int cp_of(int c) { return c <= 4 ? 4 : 5; }
+__host__ __device__ inline int gl_of(int CP) { return CP <= 8 ? 8 : 4; }
+
+__host__ __device__ inline Geom make_geom(int d, int c, int K, int L, int shared_cb)
+{
+    Geom g;
+    g.d = d; g.c = c; g.K = K; g.L = L; g.shared_cb = shared_cb;
+    g.CP = cp_of(c);
+    g.GL = gl_of(g.CP);
+    g.GP = ((g.GL * g.CP + 15) / 16) * 16;
+    g.GS = ((6 * g.CP * g.GL + 31) / 32) * 32;
+    g.NLG = (L + g.GL - 1) / g.GL;
+    g.NOG = g.NLG * (g.GP / 16);
+    g.KSA = d / 32;
+    g.NKC = (6 * g.CP + 31) / 32;
+    g.KT = (K + 15) / 16;
+    g.KTP = ((g.KT + 3) / 4) * 4;        // whole groups of 4 row tiles (pad rows are masked out in the scan)
+    g.NET = d / 16;
+    g.NKSC = g.NLG * (g.GS / 32);        // k-steps of the reconstruction at full depth
+    g.GB = (g.CP * g.CP + 3) & ~3;       // floats per Gram block
+    return g;
+}
+
+__host__ __device__ inline bool gram_shape_ok(int d, int c, int K, int L)
+{
+    return d >= 128 && d % 128 == 0 && d <= 8192 && c >= 1 && c <= GRAM_MAX_C && K >= 1 && K <= 65536 && L >= 1 &&
+           L <= GRAM_MAX_L;
+}
+
+// k-steps of the reconstruction for `levels` levels
+__host__ __device__ inline int nks_recon(const Geom &g, int levels)
+{
+    const int full = levels / g.GL, rem = levels % g.GL;
+    return full * (g.GS / 32) + (6 * g.CP * rem + 31) / 32;
+}
+
+inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct GLayout {
+    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, total;
+};
+
+GLayout make_glayout(const Geom &g)
+{
+    GLayout lo;
+    size_t off = 256;
+    lo.win_img = off;     off += al256((size_t)g.KSA * g.NOG * 3 * 1024);
+    lo.kconst = off;      off += al256(sizeof(float) * (size_t)g.NOG * 16);
+    lo.gneg = off;        off += al256(sizeof(float) * (size_t)g.L * g.L * g.GB);
+    const int lcb = g.shared_cb ? 1 : g.L;
+    lo.cb_img = off;      off += al256((size_t)lcb * g.KTP * g.NKC * 1024);
+    lo.cb_f32 = off;      off += al256(sizeof(float) * ((size_t)lcb * g.K * g.c + 64 * g.c));   // + slack: quad-row reads of pad rows
+    lo.wout_img = off;    off += al256((size_t)g.NET * g.NKSC * 1024);
+    lo.bias_prefix = off; off += al256(sizeof(float) * (size_t)g.L * g.d);
+    lo.total = off;
+    return lo;
+}
+
+struct GHeader {
+    int magic, d, c, K, L, shared_cb, pad[58];
+};
+static_assert(sizeof(GHeader) == 256, "header");
+
+// ------------------------------------------------------------------------------------------------ bf16 pieces
+// fp32 = hi + mid + lo exactly, each piece a bf16 (truncation: hi keeps the top 8 significant bits, the
+// remainders are exact in fp32 and hold <= 16 and <= 8 significant bits).
+__host__ __device__ inline void split3(float v, unsigned &hi, unsigned &mid, unsigned &lo)
+{
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    hi = b & 0xffff0000u;
+    const float r1 = v - __builtin_bit_cast(float, hi);
+    mid = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, mid);
+    lo = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
+}
+__device__ inline uint16_t piece_of(float v, int part)
+{
+    unsigned h, m, l;
+    split3(v, h, m, l);
+    return (uint16_t)((part == 0 ? h : part == 1 ? m : l) >> 16);
+}
+// the six products kept per component: (A piece, B piece); dropped: mid*lo, lo*mid, lo*lo (<= 2^-24 relative)
+__device__ constexpr int APART[6] = {0, 0, 1, 0, 2, 1};
+// B side per component, slot order: hi mid hi lo hi mid  -> dwords {hi|mid, hi|lo, hi|mid}
+
+// bit casts by value: __builtin_bit_cast applied directly to an ext-vector ELEMENT lvalue (v[2]) reads element 0
+// with this hipcc (seen in the ISA), so every reinterpretation goes through a by-value helper
+__device__ __forceinline__ float f32_of(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned u32_of(float f) { return __builtin_bit_cast(unsigned, f); }
+
+// low half = top 16 bits of a, high half = top 16 bits of b
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// 1 KiB global -> LDS, lane i moves 16 bytes from its own address to lds_base + 16 i
+__device__ __forceinline__ void glds16(const void *gsrc_lane, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ pack kernels
+// W_in image: fragment (ks, u, part) = 1 KiB = A operand of v_mfma_f32_16x16x32_bf16: lane 16g+r holds row r
+// (output 16u+r), k = 8g+j (element 32ks+8g+j).
+__global__ void gram_pack_win_kernel(Geom g, const float *w_in, uint16_t *img)
+{
+    const size_t total = (size_t)g.KSA * g.NOG * 3 * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t f = i >> 9;
+        const int part = (int)(f % 3); f /= 3;
+        const int u = (int)(f % g.NOG);
+        const int ks = (int)(f / g.NOG);
+        const int o = 16 * u + (lane & 15), e = 32 * ks + 8 * (lane >> 4) + j;
+        const int lg = o / g.GP, rem = o % g.GP, li = rem / g.CP, jj = rem % g.CP, l = lg * g.GL + li;
+        float v = 0.0f;
+        if (rem < g.GL * g.CP && l < g.L && jj < g.c) v = w_in[((size_t)l * g.c + jj) * g.d + e];
+        img[i] = piece_of(v, part);
+    }
+}
+
+// Gram blocks, negated:  gneg[m][l2][j][i] = -(W_in[l2] W_out[m])[j][i]   (fp64 sum, rounded once), l2 > m
+// kconst[o] = b_in[l][j] - sum_{m<l} W_in[l][j][:] . b_out[m][:]
+// grid = (L, L + 1): y < L -> block (m = x, l2 = y);  y == L -> kconst of level x
+__global__ void gram_pack_gram_kernel(Geom g, const float *w_in, const float *b_in, const float *w_out, const float *b_out,
+                                      float *gneg, float *kconst)
+{
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    if ((int)blockIdx.y < g.L) {
+        const int m = blockIdx.x, l2 = blockIdx.y;
+        float *blk = gneg + ((size_t)m * g.L + l2) * g.GB;
+        if (l2 <= m) {
+            if (t < g.GB) blk[t] = 0.0f;
+            return;
+        }
+        for (int j = 0; j < g.CP; ++j)
+            for (int i = 0; i < g.CP; ++i) {
+                double s = 0.0;
+                if (j < g.c && i < g.c)
+                    for (int e = t; e < g.d; e += 256)
+                        s += (double)w_in[((size_t)l2 * g.c + j) * g.d + e] * (double)w_out[((size_t)m * g.d + e) * g.c + i];
+                red[t] = s;
+                __syncthreads();
+                for (int st = 128; st > 0; st >>= 1) {
+                    if (t < st) red[t] += red[t + st];
+                    __syncthreads();
+                }
+                if (t == 0) blk[j * g.CP + i] = (float)(-red[0]);
+                __syncthreads();
+            }
+        if (t >= g.CP * g.CP && t < g.GB) blk[t] = 0.0f;
+    } else {
+        const int l = blockIdx.x;
+        for (int j = 0; j < g.CP; ++j) {
+            double s = 0.0;
+            if (j < g.c)
+                for (int e = t; e < g.d; e += 256) {
+                    double bp = 0.0;
+                    for (int m = 0; m < l; ++m) bp += (double)b_out[(size_t)m * g.d + e];
+                    s += (double)w_in[((size_t)l * g.c + j) * g.d + e] * bp;
+                }
+            red[t] = s;
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) {
+                if (t < st) red[t] += red[t + st];
+                __syncthreads();
+            }
+            if (t == 0) {
+                const int o = (l / g.GL) * g.GP + (l % g.GL) * g.CP + j;
+                kconst[o] = j < g.c ? (float)((double)b_in[(size_t)l * g.c + j] - red[0]) : 0.0f;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// codebook image: fragment (lcb, tile, ks) = A operand: lane 16g+r holds codebook row 16 tile + r, slots
+// 32ks+8g+j; slot s -> component s/6, term s%6 -> piece APART[term] of codebook[row][component].
+__global__ void gram_pack_cb_kernel(Geom g, const float *codebook, uint16_t *img, float *cb_f32)
+{
+    const int lcb = g.shared_cb ? 1 : g.L;
+    const size_t total = (size_t)lcb * g.KTP * g.NKC * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t f = i >> 9;
+        const int ks = (int)(f % g.NKC); f /= g.NKC;
+        const int tile = (int)(f % g.KTP);
+        const int lv = (int)(f / g.KTP);
+        const int row = 16 * tile + (lane & 15), s = 32 * ks + 8 * (lane >> 4) + j;
+        const int comp = s / 6, term = s % 6;
+        float v = 0.0f;
+        if (row < g.K && comp < g.c) v = codebook[((size_t)lv * g.K + row) * g.c + comp];
+        img[i] = piece_of(v, APART[term]);
+    }
+    const size_t nf = (size_t)lcb * g.K * g.c, nall = nf + 64 * g.c;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nall; i += (size_t)gridDim.x * blockDim.x)
+        cb_f32[i] = i < nf ? codebook[i] : 0.0f;
+}
+
+// W_out image: fragment (et, ks) = A operand: lane 16g+r holds element 16et+r, slots 32ks+8g+j; the slot of
+// (level l, component jj, term) is (l / GL) * GS + ((l % GL) * CP + jj) * 6 + term.
+__global__ void gram_pack_wout_kernel(Geom g, const float *w_out, uint16_t *img)
+{
+    const size_t total = (size_t)g.NET * g.NKSC * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t f = i >> 9;
+        const int ks = (int)(f % g.NKSC);
+        const int et = (int)(f / g.NKSC);
+        const int e = 16 * et + (lane & 15), s = 32 * ks + 8 * (lane >> 4) + j;
+        const int lg = s / g.GS, rs = s % g.GS;
+        const int term = rs % 6, cj = rs / 6, li = cj / g.CP, jj = cj % g.CP, l = lg * g.GL + li;
+        float v = 0.0f;
+        if (rs < 6 * g.CP * g.GL && l < g.L && jj < g.c) v = w_out[((size_t)l * g.d + e) * g.c + jj];
+        img[i] = piece_of(v, APART[term]);
+    }
+}
+
+__global__ void gram_pack_bias_kernel(Geom g, const float *b_out, float *bias_prefix)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.d) return;
+    double s = 0.0;
+    for (int l = 0; l < g.L; ++l) {
+        s += (double)b_out[(size_t)l * g.d + e];
+        bias_prefix[(size_t)l * g.d + e] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel A: project
+struct ProjParams {
+    const void *x;
+    const uint16_t *win_img;
+    float *P;              // [NOG][tok_pad][16]
+    long long n_tokens, tok_pad;
+    int d, NOG, KSA;
+};
+
+constexpr int A_KC = 4;     // k-steps per staged weight chunk
+constexpr int A_TT = 2;     // 16-token tiles per wave
+constexpr int A_NW = 4;     // waves per workgroup
+constexpr int A_BUF = A_KC * 9 * 1024;
+
+// x fragment of one k-step as bf16 pieces (B operand: lane 16g+n holds token n, elements 32ks+8g+0..7)
+template <int XT> struct XFrag;
+template <> struct XFrag<RQAE_X_BF16> {
+    static constexpr int NP = 1;
+    u32x4 raw;
+    __device__ __forceinline__ void load(const void *x, long long row, int d, int e0) { raw = *reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(x) + row * d + e0); }
+    __device__ __forceinline__ void parts(u32x4 (&o)[3]) const { o[0] = raw; }
+};
+template <> struct XFrag<RQAE_X_F16> {
+    static constexpr int NP = 2;
+    u32x4 raw;
+    __device__ __forceinline__ void load(const void *x, long long row, int d, int e0) { raw = *reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(x) + row * d + e0); }
+    __device__ __forceinline__ void parts(u32x4 (&o)[3]) const
+    {
+        // fp16 (11 significant bits) = hi (8 bits) + lo (<= 3 bits), both exact bf16
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            const unsigned rw = raw[w];
+            const h2 hv = __builtin_bit_cast(h2, rw);
+            const float a = (float)hv[0], b = (float)hv[1];
+            const unsigned ah = __builtin_bit_cast(unsigned, a) & 0xffff0000u, bh = __builtin_bit_cast(unsigned, b) & 0xffff0000u;
+            const float al = a - __builtin_bit_cast(float, ah), bl = b - __builtin_bit_cast(float, bh);
+            o[0][w] = pack_hi16(ah, bh);
+            o[1][w] = pack_hi16(__builtin_bit_cast(unsigned, al), __builtin_bit_cast(unsigned, bl));
+        }
+    }
+};
+template <> struct XFrag<RQAE_X_F32> {
+    static constexpr int NP = 3;
+    u32x4 raw0, raw1;
+    __device__ __forceinline__ void load(const void *x, long long row, int d, int e0)
+    {
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(static_cast<const float *>(x) + row * d + e0);
+        raw0 = p[0]; raw1 = p[1];
+    }
+    __device__ __forceinline__ void parts(u32x4 (&o)[3]) const
+    {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = f32_of(w < 2 ? raw0[2 * w] : raw1[2 * w - 4]);
+            const float b = f32_of(w < 2 ? raw0[2 * w + 1] : raw1[2 * w - 3]);
+            unsigned ah, am, al, bh, bm, bl;
+            split3(a, ah, am, al);
+            split3(b, bh, bm, bl);
+            o[0][w] = pack_hi16(ah, bh);
+            o[1][w] = pack_hi16(am, bm);
+            o[2][w] = pack_hi16(al, bl);
+        }
+    }
+};
+
+// One workgroup = 4 waves x 32 tokens, up to 3 output groups (9 weight fragments per k-step: 3 groups x 3
+// pieces).  The weight image streams L2 -> LDS by LDS-DMA in chunks of A_KC k-steps, double buffered; x goes
+// straight to registers (every x byte is used by exactly one wave), one chunk ahead.
+template <int XT>
+__global__ __launch_bounds__(A_NW * 64) void gram_project_kernel(ProjParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, n = lane & 15;
+    const int ug0 = blockIdx.y * 3;
+    const int ng = p.NOG - ug0 < 3 ? p.NOG - ug0 : 3;
+    const long long tb = ((long long)blockIdx.x * A_NW + wave) * (16 * A_TT);
+    long long row[A_TT];
+#pragma unroll
+    for (int T = 0; T < A_TT; ++T) {
+        const long long r = tb + 16 * T + n;
+        row[T] = r < p.n_tokens ? r : p.n_tokens - 1;
+    }
+    f32x4 acc[3][3][A_TT];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int T = 0; T < A_TT; ++T) acc[u][pp][T] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.KSA / A_KC;
+    auto stage = [&](int cc, int buf) {
+        const int npc = A_KC * ng * 3;
+        for (int q = wave; q < npc; q += A_NW) {
+            const int k = q / (ng * 3), rem = q - k * (ng * 3), u = rem / 3, pp = rem - 3 * u;
+            const uint16_t *src = p.win_img + ((((size_t)(cc * A_KC + k) * p.NOG + ug0 + u) * 3 + pp) * 512) + lane * 8;
+            glds16(src, smem + buf * A_BUF + ((k * 3 + u) * 3 + pp) * 1024);
+        }
+    };
+    XFrag<XT> xc[A_KC][A_TT], xn[A_KC][A_TT];
+    stage(0, 0);
+#pragma unroll
+    for (int k = 0; k < A_KC; ++k)
+#pragma unroll
+        for (int T = 0; T < A_TT; ++T) xc[k][T].load(p.x, row[T], p.d, 32 * k + 8 * g);
+    __syncthreads();
+
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int buf = cc & 1;
+        if (cc + 1 < nchunks) {
+            stage(cc + 1, buf ^ 1);
+#pragma unroll
+            for (int k = 0; k < A_KC; ++k)
+#pragma unroll
+                for (int T = 0; T < A_TT; ++T) xn[k][T].load(p.x, row[T], p.d, 32 * ((cc + 1) * A_KC + k) + 8 * g);
+        }
+        const char *wb = smem + buf * A_BUF + lane * 16;
+#pragma unroll
+        for (int k = 0; k < A_KC; ++k) {
+            u32x4 xp[A_TT][3];
+#pragma unroll
+            for (int T = 0; T < A_TT; ++T) xc[k][T].parts(xp[T]);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (u < ng) {
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp) {
+                        const u32x4 a = *reinterpret_cast<const u32x4 *>(wb + ((k * 3 + u) * 3 + pp) * 1024);
+#pragma unroll
+                        for (int T = 0; T < A_TT; ++T)
+#pragma unroll
+                            for (int xq = 0; xq < XFrag<XT>::NP; ++xq) acc[u][pp][T] = mfma16(a, xp[T][xq], acc[u][pp][T]);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // next chunk landed (the barrier's fence drains the DMA), this buffer is free
+#pragma unroll
+        for (int k = 0; k < A_KC; ++k)
+#pragma unroll
+            for (int T = 0; T < A_TT; ++T) xc[k][T] = xn[k][T];
+    }
+    // D layout: lane (g, n) holds outputs 4g..4g+3 of token n; pieces summed small to large
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        if (u < ng) {
+#pragma unroll
+            for (int T = 0; T < A_TT; ++T) {
+                const long long tok = tb + 16 * T + n;
+                if (tok < p.n_tokens) {
+                    const f32x4 v = (acc[u][2][T] + acc[u][1][T]) + acc[u][0][T];
+                    *reinterpret_cast<f32x4 *>(p.P + (((size_t)(ug0 + u) * p.tok_pad + tok) * 16 + 4 * g)) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel B: levels
+struct LevParams {
+    float *P;                 // [NOG][tok_pad][16]; columns of later level groups are updated in place
+    const float *kconst;      // [NOG*16]
+    const float *gneg;        // [L][L][GB]
+    const uint16_t *cb_img;   // [lcb][KTP][NKC][512]
+    const float *cb_f32;      // [lcb][K][c]
+    unsigned *cvimg;          // [nks][tok_pad][16 dwords]: B operand rows of the reconstruction
+    long long *idx;           // [n_tokens][levels]
+    long long n_tokens, tok_pad, ntiles;
+    int levels, L, K, KTP, c, shared_cb;
+};
+
+// One wave = 64 tokens, one token per lane for everything in c-space; for the cosine contraction the wave's
+// tokens are 4 MFMA column tiles.  S[row][token] = sum_slots cb_piece[row][slot] * q_piece[token][slot] over the
+// 6c slots of one (NKC) k-step(s): six bf16 x bf16 products per component reproduce the fp32 x fp32 product to
+// 2^-24.  Scores are unnormalised (argmax of cos == argmax of the dot product for a positive norm); a zero,
+// NaN or infinite projection takes index 0 as torch.argmax over NaNs does (rqae/model.py:182,188).
+template <int CP, int NW, bool MULTI>
+__global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
+{
+    constexpr int GL = CP <= 8 ? 8 : 4;
+    constexpr int GP = ((GL * CP + 15) / 16) * 16;
+    constexpr int GS = ((6 * CP * GL + 31) / 32) * 32;
+    constexpr int NKC = (6 * CP + 31) / 32;
+    constexpr int GB = (CP * CP + 3) & ~3;
+    constexpr int XCHB = NKC * 4096;
+    static_assert(NKC == 1, "one k-step per cosine contraction in the instantiated shapes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, n = lane & 15;
+    const int imgb = p.KTP * NKC * 1024;
+    char *cbl = smem;
+    char *xch = smem + imgb + wave * XCHB;
+    const int c = p.c;
+
+    // resident codebook image (shared codebooks: one image for every level)
+    for (int q = wave; q < p.KTP * NKC; q += NW) glds16(p.cb_img + (size_t)q * 512 + lane * 8, cbl + q * 1024);
+    __syncthreads();
+
+    const int nlg = (p.levels + GL - 1) / GL;
+    const int wq = (lane >> 2) & 3;            // row quad of this lane's token inside its 16-token tile
+    for (long long tile = (long long)blockIdx.x * NW + wave; tile < p.ntiles; tile += (long long)gridDim.x * NW) {
+        const long long t = tile * 64 + lane;  // < tok_pad
+        for (int lg = 0; lg < nlg; ++lg) {
+            float Q[GL][CP];
+            {
+                float buf[GP];
+#pragma unroll
+                for (int u = 0; u < GP / 16; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const f32x4 w = *reinterpret_cast<const f32x4 *>(p.P + (((size_t)(lg * (GP / 16) + u) * p.tok_pad + t) * 16 + 4 * v));
+                        const f32x4 kc = *reinterpret_cast<const f32x4 *>(p.kconst + (lg * GP + 16 * u + 4 * v));
+                        buf[16 * u + 4 * v + 0] = w[0] + kc[0];
+                        buf[16 * u + 4 * v + 1] = w[1] + kc[1];
+                        buf[16 * u + 4 * v + 2] = w[2] + kc[2];
+                        buf[16 * u + 4 * v + 3] = w[3] + kc[3];
+                    }
+#pragma unroll
+                for (int li = 0; li < GL; ++li)
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) Q[li][j] = buf[li * CP + j];
+            }
+            float cvh[GL][CP];
+            int codes[GL];
+            unsigned img[GS / 2];                // this group's reconstruction slots, two bf16 per dword
+#pragma unroll
+            for (int i = 0; i < GS / 2; ++i) img[i] = 0u;
+
+            static_for<0, GL>([&](auto li_c) {
+                constexpr int li = decltype(li_c)::value;
+                const int l = lg * GL + li;
+                if (l < p.levels) {
+                    float q[CP];
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) q[j] = Q[li][j];
+                    float n2 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
+                    const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
+
+                    // ---- B operand rows of this wave's tokens: 32 slots = 64 bytes per token, through LDS
+                    unsigned dw[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dw[i] = 0u;
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) {
+                        unsigned h, m, lo;
+                        split3(q[j], h, m, lo);
+                        dw[3 * j] = pack_hi16(h, m);
+                        dw[3 * j + 1] = pack_hi16(h, lo);
+                        dw[3 * j + 2] = dw[3 * j];
+                    }
+#pragma unroll
+                    for (int pc = 0; pc < 4; ++pc) {
+                        const int pos = (pc + 2 * wq) & 3;   // bank-conflict-free placement of the four 16-byte pieces
+                        *reinterpret_cast<u32x4 *>(xch + lane * 64 + pos * 16) = u32x4{dw[4 * pc], dw[4 * pc + 1], dw[4 * pc + 2], dw[4 * pc + 3]};
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    u32x4 B[4];
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) {
+                        const int pos = (g + 2 * ((n >> 2) & 3)) & 3;
+                        B[T] = *reinterpret_cast<const u32x4 *>(xch + (16 * T + n) * 64 + pos * 16);
+                    }
+
+                    // ---- scan: running maximum per (lane, token tile) over groups of 4 row tiles (16 rows per lane)
+                    float best[4];
+                    int bgrp[4];
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) { best[T] = -INFINITY; bgrp[T] = 0; }
+                    const char *cbl_l = cbl;   // shared codebook: same image every level
+                    const int ngrp = p.KTP / 4;
+                    u32x4 an[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u32x4 *>(cbl_l + i * NKC * 1024 + lane * 16);
+                    for (int grp = 0; grp < ngrp; ++grp) {
+                        float mx[4];
+                        const bool tail = (grp == ngrp - 1) && (p.K % 64 != 0);
+                        u32x4 a[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[i] = an[i];
+                        if (grp + 1 < ngrp) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u32x4 *>(cbl_l + (((grp + 1) * 4 + i) * NKC) * 1024 + lane * 16);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            // four independent MFMAs back to back (one per token tile), then their maxima: the first
+                            // result is ready by the time the fourth has issued
+                            f32x4 s[4];
+#pragma unroll
+                            for (int T = 0; T < 4; ++T) s[T] = mfma16(a[i], B[T], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                            for (int T = 0; T < 4; ++T) {
+                                if (tail) {
+                                    const int r0 = 16 * (grp * 4 + i) + 4 * g;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) s[T][r] = (r0 + r < p.K) ? s[T][r] : -INFINITY;
+                                }
+                                // IEEE-754-2019 maximum (v_maximum3_f32): a NaN score poisons the maximum, which then never
+                                // beats `best`; the level takes index 0 through okq
+                                const float m012 = __builtin_elementwise_maximum(__builtin_elementwise_maximum(s[T][0], s[T][1]), s[T][2]);
+                                if (i == 0) mx[T] = __builtin_elementwise_maximum(m012, s[T][3]);
+                                else mx[T] = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m012, s[T][3]), mx[T]);
+                            }
+                        }
+#pragma unroll
+                        for (int T = 0; T < 4; ++T) {
+                            const bool up = mx[T] > best[T];
+                            best[T] = up ? mx[T] : best[T];
+                            bgrp[T] = up ? grp : bgrp[T];
+                        }
+                    }
+                    // ---- the four lanes (g) of a token hand their (maximum, group) to the token's own lane
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) {
+                        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                        *reinterpret_cast<u32x2 *>(xch + ((16 * T + n) * 4 + g) * 8) = u32x2{u32_of(best[T]), (unsigned)bgrp[T]};
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const u32x4 h0 = *reinterpret_cast<const u32x4 *>(xch + lane * 32);
+                    const u32x4 h1 = *reinterpret_cast<const u32x4 *>(xch + lane * 32 + 16);
+                    float bv = f32_of(h0[0]);
+                    int bgr = (int)h0[1], bg = 0;
+                    bool amb = false;
+                    {
+                        const float v1 = f32_of(h0[2]), v2 = f32_of(h1[0]), v3 = f32_of(h1[2]);
+                        const int g1 = (int)h0[3], g2 = (int)h1[1], g3 = (int)h1[3];
+                        const float vv[3] = {v1, v2, v3};
+                        const int gg[3] = {g1, g2, g3};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const bool gt = vv[k] > bv, eq = vv[k] == bv;
+                            const bool take = gt || (eq && gg[k] < bgr);
+                            amb = take ? false : (amb || (eq && gg[k] == bgr));
+                            bv = take ? vv[k] : bv;
+                            bg = take ? k + 1 : bg;
+                            bgr = take ? gg[k] : bgr;
+                        }
+                    }
+                    if (!okq) { bgr = 0; bg = 0; amb = false; }
+                    // ---- the 16 rows behind that maximum, rescored in fp32 (k-ordered fma chain): first maximum wins
+                    const float *cbf = p.cb_f32;   // shared codebook
+                    int brow = 64 * bgr + 4 * bg;
+                    float bsc = -INFINITY;
+                    auto rescore4 = [&](int r0) {
+                        float f[4 * CP];
+                        if (CP == 4 || c == CP) {
+                            // rows are c floats apart: a row quad is c aligned float4s
+                            const f32x4 *qp = reinterpret_cast<const f32x4 *>(cbf + (size_t)r0 * c);
+#pragma unroll
+                            for (int w = 0; w < CP; ++w) {
+                                const f32x4 v = (c == CP) ? qp[w] : f32x4{0.f, 0.f, 0.f, 0.f};
+                                f[4 * w] = v[0]; f[4 * w + 1] = v[1]; f[4 * w + 2] = v[2]; f[4 * w + 3] = v[3];
+                            }
+                        }
+                        if (c != CP) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int j = 0; j < CP; ++j) f[r * CP + j] = j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float s = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < CP; ++j) s = __builtin_fmaf(f[r * CP + j], q[j], s);
+                            const bool up = (s > bsc) && (r0 + r < p.K);
+                            bsc = up ? s : bsc;
+                            brow = up ? r0 + r : brow;
+                        }
+                    };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rescore4(16 * (4 * bgr + i) + 4 * bg);
+                    if (amb) {
+                        // equal maxima in one 64-row block on several lanes (duplicate rows): rescan the block in row order
+                        brow = 64 * bgr;
+                        bsc = -INFINITY;
+                        for (int r0 = 64 * bgr; r0 < 64 * bgr + 64; r0 += 4) rescore4(r0);
+                    }
+                    if (!okq) brow = 0;
+                    codes[li] = brow;
+                    // ---- straight-through value (rqae/model.py:218-220) and its bf16 pieces for the reconstruction
+                    float cvp[CP];
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) {
+                        const float cv = j < c ? cbf[(size_t)brow * c + j] : 0.0f;
+                        const float df = cv - q[j];
+                        cvp[j] = q[j] + df;
+                        if (MULTI) cvh[li][j] = cvp[j];
+                        unsigned h, m, lo;
+                        split3(cvp[j], h, m, lo);
+                        const int s0 = (li * CP + j) * 3;
+                        img[s0] = pack_hi16(h, m);
+                        img[s0 + 1] = pack_hi16(h, lo);
+                        img[s0 + 2] = img[s0];
+                    }
+                    // ---- later levels of this group see the level just applied
+#pragma unroll
+                    for (int li2 = li + 1; li2 < GL; ++li2) {
+                        const int l2 = lg * GL + li2;
+                        if (l2 < p.levels) {
+                            const float *gb = p.gneg + ((size_t)l * p.L + l2) * GB;
+#pragma unroll
+                            for (int j = 0; j < CP; ++j)
+#pragma unroll
+                                for (int i = 0; i < CP; ++i) Q[li2][j] = __builtin_fmaf(gb[j * CP + i], cvp[i], Q[li2][j]);
+                        }
+                    }
+                    // ---- reconstruction operand rows: every k-step this level completed (all of them after the last level)
+                    {
+                        const int ks_lo = (3 * CP * li) / 16;
+                        const int ks_hi = (l == p.levels - 1 || li == GL - 1) ? (3 * CP * (li + 1) + 15) / 16 : (3 * CP * (li + 1)) / 16;
+#pragma unroll
+                        for (int ks = ks_lo; ks < GS / 32; ++ks)
+                            if (ks < ks_hi) {
+                                unsigned *dst = p.cvimg + (((size_t)(lg * (GS / 32) + ks) * p.tok_pad + t) * 16);
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                    *reinterpret_cast<u32x4 *>(dst + 4 * v) = u32x4{img[16 * ks + 4 * v], img[16 * ks + 4 * v + 1], img[16 * ks + 4 * v + 2], img[16 * ks + 4 * v + 3]};
+                            }
+                    }
+                } else {
+                    codes[li] = 0;
+                    if (MULTI) {
+#pragma unroll
+                        for (int j = 0; j < CP; ++j) cvh[li][j] = 0.0f;
+                    }
+                }
+            });
+            // ---- codes and reconstruction operand rows of this group
+            if (t < p.n_tokens) {
+#pragma unroll
+                for (int li = 0; li < GL; ++li)
+                    if (lg * GL + li < p.levels) p.idx[t * p.levels + lg * GL + li] = (long long)codes[li];
+            }
+            // ---- projections of the later level groups see this group's levels
+            if (MULTI)
+            for (int l2 = (lg + 1) * GL; l2 < p.levels; ++l2) {
+                const int o0 = (l2 / GL) * GP + (l2 % GL) * CP;
+                float v[CP];
+#pragma unroll
+                for (int j = 0; j < CP; ++j) v[j] = p.P[((size_t)((o0 + j) >> 4) * p.tok_pad + t) * 16 + ((o0 + j) & 15)];
+#pragma unroll
+                for (int li = 0; li < GL; ++li) {
+                    const float *gb = p.gneg + ((size_t)(lg * GL + li) * p.L + l2) * GB;
+#pragma unroll
+                    for (int j = 0; j < CP; ++j)
+#pragma unroll
+                        for (int i = 0; i < CP; ++i) v[j] = __builtin_fmaf(gb[j * CP + i], cvh[li][i], v[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < CP; ++j) p.P[((size_t)((o0 + j) >> 4) * p.tok_pad + t) * 16 + ((o0 + j) & 15)] = v[j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel C: reconstruct
+struct RecParams {
+    const uint16_t *wout_img;    // [NET][NKSC][512]
+    const float *bias;           // bias_prefix[levels-1][d]
+    const unsigned *cvimg;       // [nks][tok_pad][16]
+    float *out;                  // [n_tokens][d]
+    long long n_tokens, tok_pad, npairs;
+    int d, NKSC, nks, NET, ETS, nslices, LQ;
+};
+
+// Weights stationary: a workgroup keeps the W_out fragments of ETS element tiles (one slice of d) in LDS and
+// streams token groups (TT x 16 tokens per wave) through them: B = a token tile's cv pieces (registers, loaded
+// once per pair), A = LDS fragment, D = 16 elements x 16 tokens, accumulator initialised with the bias sum.
+// Lane (g, n) ends up with elements 4g..4g+3 of token n: one 16-byte store.  No barrier after the prologue.
+template <int NKS, int TT, int NW>
+__global__ __launch_bounds__(NW * 64) void gram_reconstruct_kernel(RecParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, n = lane & 15;
+    // blocks b and b + 8 share an XCD (and its L2): an XCD owns every 8th token pair and runs all slices on them
+    const int b = blockIdx.x, xcd = b & 7, w = b >> 3;
+    const int slice = w % p.nslices, lq = w / p.nslices;
+    const int et0 = slice * p.ETS;
+    const int net = p.NET - et0 < p.ETS ? p.NET - et0 : p.ETS;
+    for (int q = wave; q < net * p.nks; q += NW) {
+        const int et = q / p.nks, ks = q - et * p.nks;
+        glds16(p.wout_img + (((size_t)(et0 + et) * p.NKSC + ks) * 512) + lane * 8, smem + (et * NKS + ks) * 1024);
+    }
+    __syncthreads();
+    const long long stride = (long long)p.LQ * NW;
+    for (long long pi = (long long)lq * NW + wave;; pi += stride) {
+        const long long pair = xcd + 8 * pi;
+        if (pair >= p.npairs) break;
+        const long long tb = pair * (16 * TT);
+        u32x4 B[TT][NKS];
+#pragma unroll
+        for (int T = 0; T < TT; ++T)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                B[T][ks] = ks < p.nks ? *reinterpret_cast<const u32x4 *>(p.cvimg + (((size_t)ks * p.tok_pad + tb + 16 * T + n) * 16 + 4 * g))
+                                      : u32x4{0u, 0u, 0u, 0u};
+        for (int et = 0; et < net; ++et) {
+            const int e0 = (et0 + et) * 16 + 4 * g;
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + e0);
+            f32x4 acc[TT];
+#pragma unroll
+            for (int T = 0; T < TT; ++T) acc[T] = bias;
+            const char *wb = smem + (et * NKS) * 1024 + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks < p.nks) {
+                    const u32x4 a = *reinterpret_cast<const u32x4 *>(wb + ks * 1024);
+#pragma unroll
+                    for (int T = 0; T < TT; ++T) acc[T] = mfma16(a, B[T][ks], acc[T]);
+                }
+            }
+#pragma unroll
+            for (int T = 0; T < TT; ++T) {
+                const long long tok = tb + 16 * T + n;
+                if (tok < p.n_tokens) *reinterpret_cast<f32x4 *>(p.out + (size_t)tok * p.d + e0) = acc[T];
+            }
+        }
+    }
+}
+
+constexpr int C_NW = 8;
+constexpr int B_NW = 8;
+constexpr size_t C_LDS_BUDGET = 144 * 1024;
+
+int device_cus()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    static int cus[64];
+    if (dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+        cus[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
+struct GView {
+    Geom g;
+    const uint16_t *win_img, *cb_img, *wout_img;
+    const float *kconst, *gneg, *cb_f32, *bias_prefix;
+};
+
+// the header lives on the device; the caller passes (d, c, K, L) again and the geometry is recomputed
+GView gview(const void *packed, int d, int c, int K, int L, int shared_cb)
+{
+    GView v;
+    v.g = make_geom(d, c, K, L, shared_cb);
+    const GLayout lo = make_glayout(v.g);
+    const char *b = static_cast<const char *>(packed);
+    v.win_img = reinterpret_cast<const uint16_t *>(b + lo.win_img);
+    v.kconst = reinterpret_cast<const float *>(b + lo.kconst);
+    v.gneg = reinterpret_cast<const float *>(b + lo.gneg);
+    v.cb_img = reinterpret_cast<const uint16_t *>(b + lo.cb_img);
+    v.cb_f32 = reinterpret_cast<const float *>(b + lo.cb_f32);
+    v.wout_img = reinterpret_cast<const uint16_t *>(b + lo.wout_img);
+    v.bias_prefix = reinterpret_cast<const float *>(b + lo.bias_prefix);
+    return v;
+}
+
+constexpr long long GRAM_CHUNK = 131072;   // tokens per pass: P + cv rows of a pass stay in the 256 MiB Infinity Cache
+
+inline long long pad64(long long n) { return (n + 63) & ~63LL; }
+
+size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
+{
+    const long long ch = n_tokens < GRAM_CHUNK ? n_tokens : GRAM_CHUNK;
+    const long long tp = pad64(ch);
+    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + al256((size_t)nks_recon(g, levels) * tp * 64);
+}
+
+bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + B_NW * g.NKC * 4096 <= 150 * 1024; }
+
+int recon_nks_template(int nks)
+{
+    const int cand[] = {2, 3, 4, 6, 8, 12, 16, 24};
+    for (int v : cand)
+        if (nks <= v) return v;
+    return 0;
+}
+
+}  // namespace
+
+// ==================================================================================================== C ABI
+extern "C" {
+
+int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared)
+{
+    if (!gram_shape_ok(d, c, K, L)) return 0;
+    const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
+    return levels_resident_ok(g) ? 1 : 0;
+}
+
+size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared)
+{
+    if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared)) {
+        gfail("gram arm: unsupported shape d=%d c=%d K=%d L=%d shared=%d", d, c, K, L, codebook_shared);
+        return 0;
+    }
+    return make_glayout(make_geom(d, c, K, L, codebook_shared ? 1 : 0)).total;
+}
+
+int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
+                       const float *codebook, const float *w_out, const float *b_out, int codebook_shared, void *stream)
+{
+    if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared)) return gfail("gram_pack: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    if (!packed || !w_in || !b_in || !codebook || !w_out || !b_out) return gfail("gram_pack: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
+    const GLayout lo = make_glayout(g);
+    char *b = static_cast<char *>(packed);
+    GHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = GRAM_MAGIC; h.d = d; h.c = c; h.K = K; h.L = L; h.shared_cb = g.shared_cb;
+    G_TRY(hipMemcpyAsync(b, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    G_TRY(hipMemsetAsync(b + lo.kconst, 0, sizeof(float) * (size_t)g.NOG * 16, s));
+    hipLaunchKernelGGL(gram_pack_win_kernel, dim3(2048), dim3(256), 0, s, g, w_in, reinterpret_cast<uint16_t *>(b + lo.win_img));
+    G_TRY(hipGetLastError());
+    hipLaunchKernelGGL(gram_pack_gram_kernel, dim3((unsigned)L, (unsigned)L + 1), dim3(256), 0, s, g, w_in, b_in, w_out, b_out,
+                       reinterpret_cast<float *>(b + lo.gneg), reinterpret_cast<float *>(b + lo.kconst));
+    G_TRY(hipGetLastError());
+    hipLaunchKernelGGL(gram_pack_cb_kernel, dim3(1024), dim3(256), 0, s, g, codebook, reinterpret_cast<uint16_t *>(b + lo.cb_img),
+                       reinterpret_cast<float *>(b + lo.cb_f32));
+    G_TRY(hipGetLastError());
+    hipLaunchKernelGGL(gram_pack_wout_kernel, dim3(2048), dim3(256), 0, s, g, w_out, reinterpret_cast<uint16_t *>(b + lo.wout_img));
+    G_TRY(hipGetLastError());
+    hipLaunchKernelGGL(gram_pack_bias_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, s, g, b_out,
+                       reinterpret_cast<float *>(b + lo.bias_prefix));
+    G_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels)
+{
+    if (!gram_shape_ok(d, c, K, L) || n_tokens < 0 || levels < 1 || levels > L) {
+        gfail("gram_workspace_bytes: bad arguments");
+        return 0;
+    }
+    return ws_bytes(make_geom(d, c, K, L, 1), n_tokens > 0 ? n_tokens : 1, levels);
+}
+
+int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
+                         int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream)
+{
+    if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared)) return gfail("encode_gram: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    if (!packed || !x || !indices || !workspace) return gfail("encode_gram: null pointer");
+    if (levels < 1 || levels > L) return gfail("encode_gram: levels=%d outside 1..%d", levels, L);
+    if (x_dtype < RQAE_X_F32 || x_dtype > RQAE_X_F16) return gfail("encode_gram: bad x_dtype %d", x_dtype);
+    if (n_tokens < 0) return gfail("encode_gram: negative n_tokens");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q_out) | reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return gfail("encode_gram: x, q_out and workspace must be 16-byte aligned");
+    if (n_tokens == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const GView v = gview(packed, d, c, K, L, codebook_shared ? 1 : 0);
+    const Geom &g = v.g;
+    const int nks = nks_recon(g, levels);
+    const int nks_t = recon_nks_template(nks);
+    if (q_out && !nks_t) return gfail("encode_gram: reconstruction with %d k-steps is not instantiated (codes only: pass q_out = NULL)", nks);
+    const size_t xs = x_dtype == RQAE_X_F32 ? 4 : 2;
+    const int ncu = device_cus();
+
+    const long long chunk = n_tokens < GRAM_CHUNK ? n_tokens : GRAM_CHUNK;
+    const long long tp = pad64(chunk);
+    float *P = static_cast<float *>(workspace);
+    unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)g.NOG * tp * 16 * sizeof(float)));
+
+    for (long long t0 = 0; t0 < n_tokens; t0 += chunk) {
+        const long long nt = n_tokens - t0 < chunk ? n_tokens - t0 : chunk;
+        // ---- A
+        ProjParams pa;
+        pa.x = static_cast<const char *>(x) + (size_t)t0 * d * xs;
+        pa.win_img = v.win_img; pa.P = P; pa.n_tokens = nt; pa.tok_pad = tp; pa.d = d; pa.NOG = g.NOG; pa.KSA = g.KSA;
+        {
+            const dim3 grid((unsigned)((nt + A_NW * 16 * A_TT - 1) / (A_NW * 16 * A_TT)), (unsigned)((g.NOG + 2) / 3));
+            const size_t lds = 2 * A_BUF;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, grid, dim3(A_NW * 64), lds, s, pa);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            int rc;
+            if (x_dtype == RQAE_X_BF16) rc = go(gram_project_kernel<RQAE_X_BF16>);
+            else if (x_dtype == RQAE_X_F16) rc = go(gram_project_kernel<RQAE_X_F16>);
+            else rc = go(gram_project_kernel<RQAE_X_F32>);
+            if (rc) return rc;
+        }
+        // ---- B
+        LevParams pb;
+        pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
+        pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
+        pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
+        pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
+        {
+            const size_t lds = (size_t)g.KTP * g.NKC * 1024 + (size_t)B_NW * g.NKC * 4096;
+            long long nb = (pb.ntiles + B_NW - 1) / B_NW;
+            if (nb > 2LL * ncu) nb = 2LL * ncu;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(B_NW * 64), lds, s, pb);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            const bool multi = levels > g.GL;
+            const int rc = g.CP == 4 ? (multi ? go(gram_levels_kernel<4, B_NW, true>) : go(gram_levels_kernel<4, B_NW, false>))
+                                     : (multi ? go(gram_levels_kernel<5, B_NW, true>) : go(gram_levels_kernel<5, B_NW, false>));
+            if (rc) return rc;
+        }
+        // ---- C
+        if (q_out) {
+            RecParams pc;
+            pc.wout_img = v.wout_img; pc.bias = v.bias_prefix + (size_t)(levels - 1) * d; pc.cvimg = cvimg;
+            pc.out = q_out + (size_t)t0 * d;
+            const int ctt = nks_t <= 8 ? 2 : 1;   // token tiles per wave: the cv pieces of a wave's tokens stay in registers
+            pc.n_tokens = nt; pc.tok_pad = tp; pc.npairs = (nt + 16 * ctt - 1) / (16 * ctt);
+            pc.d = d; pc.NKSC = g.NKSC; pc.nks = nks; pc.NET = g.NET;
+            int ets = (int)(C_LDS_BUDGET / ((size_t)nks_t * 1024));
+            if (ets > g.NET) ets = g.NET;
+            pc.ETS = ets;
+            pc.nslices = (g.NET + ets - 1) / ets;
+            int lq = ncu / (8 * pc.nslices);
+            if (lq < 1) lq = 1;
+            // no more workgroups than there are token pairs to hand out
+            while (lq > 1 && 8LL * (lq - 1) * C_NW >= pc.npairs) --lq;
+            pc.LQ = lq;
+            const size_t lds = (size_t)ets * nks_t * 1024;
+            const unsigned nb = 8u * pc.nslices * lq;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(C_NW * 64), lds, s, pc);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            int rc = 1;
+            switch (nks_t) {
+            case 2: rc = go(gram_reconstruct_kernel<2, 2, C_NW>); break;
+            case 3: rc = go(gram_reconstruct_kernel<3, 2, C_NW>); break;
+            case 4: rc = go(gram_reconstruct_kernel<4, 2, C_NW>); break;
+            case 6: rc = go(gram_reconstruct_kernel<6, 2, C_NW>); break;
+            case 8: rc = go(gram_reconstruct_kernel<8, 2, C_NW>); break;
+            case 12: rc = go(gram_reconstruct_kernel<12, 1, C_NW>); break;
+            case 16: rc = go(gram_reconstruct_kernel<16, 1, C_NW>); break;
+            case 24: rc = go(gram_reconstruct_kernel<24, 1, C_NW>); break;
+            default: return gfail("encode_gram: no reconstruct kernel for %d k-steps", nks_t);
+            }
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -28,9 +28,9 @@ constexpr size_t LDS_CODEBOOK_BUDGET = 96 * 1024;
 // d = 2304, packed-VALU arm -- built with the ILP-first machine scheduler, and rqae_hip.hip -- everything else --
 // with the default one.  They share the error text and one launcher.
 #ifdef RQAE_TU_MAIN
-extern __attribute__((visibility("hidden"))) thread_local char rqae_g_err[512];
+extern __attribute__((visibility("hidden"))) __thread char rqae_g_err[512];   // __thread, not thread_local: no TLS init wrapper (a hidden weak _ZTH call crashes)
 #else
-__attribute__((visibility("hidden"))) thread_local char rqae_g_err[512] = "";
+__attribute__((visibility("hidden"))) __thread char rqae_g_err[512] = "";
 #endif
 extern "C" __attribute__((visibility("hidden"))) int rqae_main_tu_launch(int c, const void *enc_params, void *stream);
 namespace {

@@ -24,6 +24,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -384,7 +385,7 @@ template <int XT>
 __global__ __launch_bounds__(A_NW * 64) void gram_project_kernel(ProjParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, n = lane & 15;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;   // wave: provably uniform -> scalar branches
     const int ug0 = blockIdx.y * 3;
     const int ng = p.NOG - ug0 < 3 ? p.NOG - ug0 : 3;
     const long long tb = ((long long)blockIdx.x * A_NW + wave) * (16 * A_TT);
@@ -499,14 +500,19 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
     constexpr int XCHB = NKC * 4096;
     static_assert(NKC == 1, "one k-step per cosine contraction in the instantiated shapes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, n = lane & 15;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;   // wave: provably uniform -> scalar branches
     const int imgb = p.KTP * NKC * 1024;
-    char *cbl = smem;
-    char *xch = smem + imgb + wave * XCHB;
     const int c = p.c;
+    const int cbfb = ((p.K + 64) * c * 4 + 15) & ~15;   // fp32 codebook (+ 64 pad rows for the quad reads of the last block)
+    char *cbl = smem;
+    float *cbf_lds = reinterpret_cast<float *>(smem + imgb);
+    char *xch = smem + imgb + cbfb + wave * XCHB;
 
     // resident codebook image (shared codebooks: one image for every level)
     for (int q = wave; q < p.KTP * NKC; q += NW) glds16(p.cb_img + (size_t)q * 512 + lane * 8, cbl + q * 1024);
+    // ... and its fp32 rows (rescoring and the straight-through value gather them: an LDS gather instead of ~20 dependent
+    // L2 round trips per level)
+    for (int i = tid; i < (p.K + 64) * c; i += NW * 64) cbf_lds[i] = p.cb_f32[i];
     __syncthreads();
 
     const int nlg = (p.levels + GL - 1) / GL;
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
                     }
                     if (!okq) { bgr = 0; bg = 0; amb = false; }
                     // ---- the 16 rows behind that maximum, rescored in fp32 (k-ordered fma chain): first maximum wins
-                    const float *cbf = p.cb_f32;   // shared codebook
+                    const float *cbf = cbf_lds;   // shared codebook, fp32 rows in LDS
                     int brow = 64 * bgr + 4 * bg;
                     float bsc = -INFINITY;
                     auto rescore4 = [&](int r0) {
@@ -782,67 +788,183 @@ struct RecParams {
     const unsigned *cvimg;       // [nks][tok_pad][16]
     float *out;                  // [n_tokens][d]
     long long n_tokens, tok_pad, npairs;
-    int d, NKSC, nks, NET, ETS, nslices, LQ;
+    int d, NKSC, nks, NET, nslices, LQ;
 };
+
+// element tiles per slice: as many (an even number) as fit 144 KiB of LDS beside NKS k-steps each
+__host__ __device__ constexpr int rec_ets(int nks_t) { return ((144 / nks_t) / 2) * 2; }
 
 // Weights stationary: a workgroup keeps the W_out fragments of ETS element tiles (one slice of d) in LDS and
 // streams token groups (TT x 16 tokens per wave) through them: B = a token tile's cv pieces (registers, loaded
-// once per pair), A = LDS fragment, D = 16 elements x 16 tokens, accumulator initialised with the bias sum.
-// Lane (g, n) ends up with elements 4g..4g+3 of token n: one 16-byte store.  No barrier after the prologue.
+// once per group, the next group's one iteration ahead), A = LDS fragment, D = 16 elements x 16 tokens, accumulator
+// initialised with the bias sum.  No barrier after the prologue.  The tile loop is unrolled at compile time and no
+// load in the steady state is conditional: with a loop (or a branch) between a load and its use hipcc drains
+// vmcnt(0), and since loads and stores retire in order that waits for every store of the previous group (measured:
+// 0.69 ms per 262 144 tokens against 0.42 ms for the bare stores).
 template <int NKS, int TT, int NW>
 __global__ __launch_bounds__(NW * 64) void gram_reconstruct_kernel(RecParams p)
 {
+    constexpr int ETS = rec_ets(NKS);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, n = lane & 15;
-    // blocks b and b + 8 share an XCD (and its L2): an XCD owns every 8th token pair and runs all slices on them
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;   // wave: provably uniform -> scalar branches
+    // blocks b and b + 8 share an XCD (and its L2): an XCD owns every 8th token group and runs all slices on them
     const int b = blockIdx.x, xcd = b & 7, w = b >> 3;
     const int slice = w % p.nslices, lq = w / p.nslices;
-    const int et0 = slice * p.ETS;
-    const int net = p.NET - et0 < p.ETS ? p.NET - et0 : p.ETS;
-    for (int q = wave; q < net * p.nks; q += NW) {
-        const int et = q / p.nks, ks = q - et * p.nks;
-        glds16(p.wout_img + (((size_t)(et0 + et) * p.NKSC + ks) * 512) + lane * 8, smem + (et * NKS + ks) * 1024);
+    const int et0 = slice * ETS;
+    const int net = p.NET - et0 < ETS ? p.NET - et0 : ETS;
+    for (int q = wave; q < ETS * NKS; q += NW) {
+        const int et = q / NKS, ks = q - et * NKS;
+        if (ks < p.nks && et < net)
+            glds16(p.wout_img + (((size_t)(et0 + et) * p.NKSC + ks) * 512) + lane * 8, smem + (et * NKS + ks) * 1024);
+        else   // k-steps past the depth in use (their cv pieces are re-reads of the last real k-step) and tiles past d: zero
+            *reinterpret_cast<u32x4 *>(smem + (et * NKS + ks) * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
     }
+    // the slice's bias sums go to LDS too: a global load inside the tile loop would wait for every store issued before it
+    float *sbias = reinterpret_cast<float *>(smem + (size_t)ETS * NKS * 1024);
+    for (int i = tid; i < ETS * 16; i += NW * 64) sbias[i] = i < net * 16 ? p.bias[et0 * 16 + i] : 0.0f;
     __syncthreads();
     const long long stride = (long long)p.LQ * NW;
-    for (long long pi = (long long)lq * NW + wave;; pi += stride) {
-        const long long pair = xcd + 8 * pi;
-        if (pair >= p.npairs) break;
+    const bool lo8 = n < 8;
+    // The cv pieces of a token group (B operand, TT x NKS x 16 bytes per lane) are loaded by inline asm one group
+    // ahead and waited for by hand.  hipcc cannot do this: loads and stores retire in order, so a compiler-tracked
+    // load issued after a group's stores is waited for with a vmcnt that also waits for those stores, and at the loop
+    // header it merges the two histories to the conservative count (ISA: vmcnt(16) = every store of the previous
+    // group done) -- measured 0.65 ms per 262 144 tokens against 0.42 ms for the bare stores.  Here the loads are
+    // invisible to hipcc's bookkeeping, the wait after a group's stores is vmcnt(#stores) (the stores of the steady
+    // state are unconditional, so their number is static), and two register sets alternate so that no copy touches a
+    // destination before its wait.
+    const unsigned lane_off = (unsigned)(n * 64 + g * 16);   // bytes inside a 16-token x 64-byte fragment row block
+    auto loadB = [&](u32x4 (&Bd)[TT][NKS], long long pair) {
         const long long tb = pair * (16 * TT);
-        u32x4 B[TT][NKS];
 #pragma unroll
         for (int T = 0; T < TT; ++T)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                B[T][ks] = ks < p.nks ? *reinterpret_cast<const u32x4 *>(p.cvimg + (((size_t)ks * p.tok_pad + tb + 16 * T + n) * 16 + 4 * g))
-                                      : u32x4{0u, 0u, 0u, 0u};
-        for (int et = 0; et < net; ++et) {
-            const int e0 = (et0 + et) * 16 + 4 * g;
-            const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + e0);
-            f32x4 acc[TT];
-#pragma unroll
-            for (int T = 0; T < TT; ++T) acc[T] = bias;
-            const char *wb = smem + (et * NKS) * 1024 + lane * 16;
-#pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                if (ks < p.nks) {
-                    const u32x4 a = *reinterpret_cast<const u32x4 *>(wb + ks * 1024);
-#pragma unroll
-                    for (int T = 0; T < TT; ++T) acc[T] = mfma16(a, B[T][ks], acc[T]);
-                }
+                const int kc = ks < p.nks ? ks : p.nks - 1;
+                // wave-uniform base in SGPRs + one per-lane 32-bit offset: no address VGPRs per load
+                const unsigned *base = p.cvimg + ((size_t)kc * p.tok_pad + tb + 16 * T) * 16;
+                // s_nop 4: the base may come out of a v_readlane (SGPR spill); VALU-written SGPR -> VMEM address needs 5
+                // wait states and hipcc pads nothing inside an asm statement (seen: memory access fault without it)
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(Bd[T][ks]) : "v"(lane_off), "s"(base) : "memory");
             }
+    };
+    auto waitB = [&](u32x4 (&Bd)[TT][NKS], auto cnt_c) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+        // name every destination so that no use is scheduled above the wait
 #pragma unroll
-            for (int T = 0; T < TT; ++T) {
-                const long long tok = tb + 16 * T + n;
-                if (tok < p.n_tokens) *reinterpret_cast<f32x4 *>(p.out + (size_t)tok * p.d + e0) = acc[T];
-            }
+        for (int T = 0; T < TT; ++T)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(Bd[T][ks])::"memory");
+    };
+    constexpr int NSTORES = (ETS / 2) * TT * 2;             // per group in the steady state
+    constexpr int WAITN = NSTORES < 63 ? NSTORES : 63;      // vmcnt is 6 bits; anything older than the newest 63 is done
+
+    // one token group: two element tiles at a time; lanes n < 8 and n >= 8 of a 16-lane row trade one accumulator (DPP
+    // row_ror:8), so that one store instruction writes 128 contiguous bytes (a whole line) for each of 8 tokens
+    auto group = [&](u32x4 (&B)[TT][NKS], u32x4 (&Bnext)[TT][NKS], long long pair) {
+        const long long tb = pair * (16 * TT);
+        float *ob[TT][2];   // row bases once per group: tile pair `ip` is then a compile-time offset of 128 ip bytes
+#pragma unroll
+        for (int T = 0; T < TT; ++T) {
+            ob[T][0] = p.out + (size_t)(tb + 16 * T + (n & 7)) * p.d + et0 * 16 + 4 * g + (lo8 ? 0 : 16);
+            ob[T][1] = ob[T][0] + (size_t)8 * p.d;
         }
+        auto tiles = [&](auto guard_c) {
+            constexpr bool GUARD = decltype(guard_c)::value;
+            static_for<0, ETS / 2>([&](auto ip) {
+                constexpr int et = 2 * decltype(ip)::value;
+                const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(sbias + et * 16 + 4 * g);
+                const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(sbias + et * 16 + 16 + 4 * g);
+                f32x4 acc0[TT], acc1[TT];
+#pragma unroll
+                for (int T = 0; T < TT; ++T) { acc0[T] = bias0; acc1[T] = bias1; }
+                const char *wb = smem + (et * NKS) * 1024 + lane * 16;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const u32x4 a0 = *reinterpret_cast<const u32x4 *>(wb + ks * 1024);
+                    const u32x4 a1 = *reinterpret_cast<const u32x4 *>(wb + (NKS + ks) * 1024);
+#pragma unroll
+                    for (int T = 0; T < TT; ++T) {
+                        acc0[T] = mfma16(a0, B[T][ks], acc0[T]);
+                        acc1[T] = mfma16(a1, B[T][ks], acc1[T]);
+                    }
+                    // keep hipcc from hoisting all 2 NKS fragment reads of the tile pair (64 VGPRs at NKS = 8)
+                    if (ks % 2 == 1) asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int T = 0; T < TT; ++T) {
+                    f32x4 s0, s1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v0 = acc0[T][r], v1 = acc1[T][r];
+                        const float snd = lo8 ? v1 : v0;
+                        const float rcv = f32_of((unsigned)__builtin_amdgcn_update_dpp(0, (int)u32_of(snd), 0x128, 0xf, 0xf, false));
+                        s0[r] = lo8 ? v0 : rcv;    // n < 8: (token n, tile et)      n >= 8: (token n - 8, tile et + 1)
+                        s1[r] = lo8 ? rcv : v1;    // n < 8: (token n + 8, tile et)  n >= 8: (token n, tile et + 1)
+                    }
+                    if (GUARD) {
+                        const int es = (et0 + et) * 16 + 4 * g + (lo8 ? 0 : 16);
+                        const long long tok0 = tb + 16 * T + (n & 7);
+                        if (tok0 < p.n_tokens && es < p.d) *reinterpret_cast<f32x4 *>(ob[T][0] + et * 16) = s0;
+                        if (tok0 + 8 < p.n_tokens && es < p.d) *reinterpret_cast<f32x4 *>(ob[T][1] + et * 16) = s1;
+                    } else {
+                        *reinterpret_cast<f32x4 *>(ob[T][0] + et * 16) = s0;
+                        *reinterpret_cast<f32x4 *>(ob[T][1] + et * 16) = s1;
+                    }
+                }
+            });
+        };
+        if (tb + 16 * TT <= p.n_tokens && net == ETS) {
+            tiles(std::false_type{});
+            waitB(Bnext, std::integral_constant<int, WAITN>{});
+        } else {   // ragged end: conditional stores, so their number is unknown
+            tiles(std::true_type{});
+            waitB(Bnext, std::integral_constant<int, 0>{});
+        }
+    };
+    u32x4 BX[TT][NKS], BY[TT][NKS];
+    long long pi = (long long)lq * NW + wave;
+    if (xcd + 8 * pi >= p.npairs) return;
+    loadB(BX, xcd + 8 * pi);
+    waitB(BX, std::integral_constant<int, 0>{});
+    for (;;) {
+        {   // group in X, next group (past the end: this one again) into Y
+            const long long pair = xcd + 8 * pi, pn = xcd + 8 * (pi + stride);
+            loadB(BY, pn < p.npairs ? pn : pair);
+            group(BX, BY, pair);
+        }
+        pi += stride;
+        if (xcd + 8 * pi >= p.npairs) break;
+        {
+            const long long pair = xcd + 8 * pi, pn = xcd + 8 * (pi + stride);
+            loadB(BX, pn < p.npairs ? pn : pair);
+            group(BY, BX, pair);
+        }
+        pi += stride;
+        if (xcd + 8 * pi >= p.npairs) break;
     }
 }
 
-constexpr int C_NW = 8;
 constexpr int B_NW = 8;
-constexpr size_t C_LDS_BUDGET = 144 * 1024;
+
+// launch geometry knobs, read from the environment ONCE (first call), for measurements only
+struct Tuning {
+    int c_tt;            // reconstruct kernel: 16-token tiles per wave (2: 8 waves per workgroup, 1: 16 waves)
+    long long chunk;     // tokens per pass
+};
+const Tuning &tuning()
+{
+    static const Tuning t = [] {
+        Tuning v;
+        v.chunk = 262144;
+        v.c_tt = 2;
+        if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
+        if (const char *e = getenv("RQAE_GRAM_CHUNK")) { const long long c = atoll(e); if (c >= 64) v.chunk = (c + 63) & ~63LL; }
+        return v;
+    }();
+    return t;
+}
 
 int device_cus()
 {
@@ -881,18 +1003,19 @@ GView gview(const void *packed, int d, int c, int K, int L, int shared_cb)
     return v;
 }
 
-constexpr long long GRAM_CHUNK = 131072;   // tokens per pass: P + cv rows of a pass stay in the 256 MiB Infinity Cache
+// tokens per pass (tuning().chunk, default 262144; measured: 65536 1.39 ms, 131072 1.15 ms, 262144 1.11 ms per 262144
+// tokens -- fewer launches beat cache residency of the intermediates)
 
 inline long long pad64(long long n) { return (n + 63) & ~63LL; }
 
 size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
 {
-    const long long ch = n_tokens < GRAM_CHUNK ? n_tokens : GRAM_CHUNK;
+    const long long ch = n_tokens < tuning().chunk ? n_tokens : tuning().chunk;
     const long long tp = pad64(ch);
     return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + al256((size_t)nks_recon(g, levels) * tp * 64);
 }
 
-bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + B_NW * g.NKC * 4096 <= 150 * 1024; }
+bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 <= 150 * 1024; }
 
 int recon_nks_template(int nks)
 {
@@ -982,7 +1105,7 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
     const size_t xs = x_dtype == RQAE_X_F32 ? 4 : 2;
     const int ncu = device_cus();
 
-    const long long chunk = n_tokens < GRAM_CHUNK ? n_tokens : GRAM_CHUNK;
+    const long long chunk = n_tokens < tuning().chunk ? n_tokens : tuning().chunk;
     const long long tp = pad64(chunk);
     float *P = static_cast<float *>(workspace);
     unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)g.NOG * tp * 16 * sizeof(float)));
@@ -1015,7 +1138,7 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
         pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
         pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
         {
-            const size_t lds = (size_t)g.KTP * g.NKC * 1024 + (size_t)B_NW * g.NKC * 4096;
+            const size_t lds = (size_t)g.KTP * g.NKC * 1024 + ((((size_t)K + 64) * c * 4 + 15) & ~(size_t)15) + (size_t)B_NW * g.NKC * 4096;
             long long nb = (pb.ntiles + B_NW - 1) / B_NW;
             if (nb > 2LL * ncu) nb = 2LL * ncu;
             auto go = [&](auto kern) -> int {
@@ -1034,38 +1157,39 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
             RecParams pc;
             pc.wout_img = v.wout_img; pc.bias = v.bias_prefix + (size_t)(levels - 1) * d; pc.cvimg = cvimg;
             pc.out = q_out + (size_t)t0 * d;
-            const int ctt = nks_t <= 8 ? 2 : 1;   // token tiles per wave: the cv pieces of a wave's tokens stay in registers
+            const int ctt = nks_t <= 8 ? tuning().c_tt : 1;   // token tiles per wave: the cv pieces of a wave's tokens stay in registers
+            const int cnw = ctt == 1 && nks_t <= 8 ? 16 : 8;  // waves per workgroup
             pc.n_tokens = nt; pc.tok_pad = tp; pc.npairs = (nt + 16 * ctt - 1) / (16 * ctt);
             pc.d = d; pc.NKSC = g.NKSC; pc.nks = nks; pc.NET = g.NET;
-            int ets = (int)(C_LDS_BUDGET / ((size_t)nks_t * 1024));
-            if (ets > g.NET) ets = g.NET;
-            pc.ETS = ets;
+            const int ets = rec_ets(nks_t);
             pc.nslices = (g.NET + ets - 1) / ets;
             int lq = ncu / (8 * pc.nslices);
             if (lq < 1) lq = 1;
-            // no more workgroups than there are token pairs to hand out
-            while (lq > 1 && 8LL * (lq - 1) * C_NW >= pc.npairs) --lq;
+            // no more workgroups than there are token groups to hand out
+            while (lq > 1 && 8LL * (lq - 1) * cnw >= pc.npairs) --lq;
             pc.LQ = lq;
-            const size_t lds = (size_t)ets * nks_t * 1024;
+            const size_t lds = (size_t)ets * nks_t * 1024 + (size_t)ets * 16 * sizeof(float);
             const unsigned nb = 8u * pc.nslices * lq;
             auto go = [&](auto kern) -> int {
                 G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kern, dim3(nb), dim3(C_NW * 64), lds, s, pc);
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(cnw * 64), lds, s, pc);
                 G_TRY(hipGetLastError());
                 return 0;
             };
             int rc = 1;
+#define REC(NKS_) (ctt == 2 ? go(gram_reconstruct_kernel<NKS_, 2, 8>) : go(gram_reconstruct_kernel<NKS_, 1, 16>))
             switch (nks_t) {
-            case 2: rc = go(gram_reconstruct_kernel<2, 2, C_NW>); break;
-            case 3: rc = go(gram_reconstruct_kernel<3, 2, C_NW>); break;
-            case 4: rc = go(gram_reconstruct_kernel<4, 2, C_NW>); break;
-            case 6: rc = go(gram_reconstruct_kernel<6, 2, C_NW>); break;
-            case 8: rc = go(gram_reconstruct_kernel<8, 2, C_NW>); break;
-            case 12: rc = go(gram_reconstruct_kernel<12, 1, C_NW>); break;
-            case 16: rc = go(gram_reconstruct_kernel<16, 1, C_NW>); break;
-            case 24: rc = go(gram_reconstruct_kernel<24, 1, C_NW>); break;
+            case 2: rc = REC(2); break;
+            case 3: rc = REC(3); break;
+            case 4: rc = REC(4); break;
+            case 6: rc = REC(6); break;
+            case 8: rc = REC(8); break;
+            case 12: rc = go(gram_reconstruct_kernel<12, 1, 8>); break;
+            case 16: rc = go(gram_reconstruct_kernel<16, 1, 8>); break;
+            case 24: rc = go(gram_reconstruct_kernel<24, 1, 8>); break;
             default: return gfail("encode_gram: no reconstruct kernel for %d k-steps", nks_t);
             }
+#undef REC
             if (rc) return rc;
         }
     }

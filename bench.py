@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the RQAE encode hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--tokens T]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--tokens T] [--arm gram|exact|auto] [--codes-only]
 
-A "step" is one RQAE.forward (codes + reconstruction, depth 8) over one batch of
-synthetic Gemma-2-2B-shaped activations already resident in HBM:
-BASELINE.json configs[1] -- 262144 tokens x d=2304 in bf16, K=1024 (c=5), depth 8.
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank encodes
-its own batch of the same size (token-sharded, weights replicated, no collective on
-the data path): weak scaling.  Rank 0 prints ONE JSON line.
+A "step" is one RQAE.forward (codes + reconstruction, depth 8) over one batch of synthetic Gemma-2-2B-shaped
+activations already resident in HBM.  N = 1: BASELINE.json configs[1] -- 262144 tokens x d=2304 in bf16, K=1024 (c=5),
+depth 8.  N > 1: configs[2]'s sharding -- every rank encodes its own 524288-token batch (4M tokens over 8 GPUs), weights
+replicated, no collective on the data path: weak scaling.  `python bench.py --gpus N` launches its own ranks (one
+process per GPU, RCCL process group for the barrier and the MAX over ranks); under torch.distributed.run it uses the
+ranks it is given.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,23 +23,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 CFG = dict(dim=2304, codebook_dim=5, codebook_size=4, num_quantizers=8)  # K = 4**5 = 1024
-WORKLOAD = "C2: Gemma-2-2B layer-12 residual stream (synthetic), d=2304, K=1024, depth=8, bf16 in"
+WORKLOAD_1 = "C2: Gemma-2-2B layer-12 residual stream (synthetic), 256k tokens, d=2304, K=1024, depth=8, bf16 in"
+WORKLOAD_N = "C3: same d/K/depth, 512k tokens per GPU token-sharded (4M over 8 GPUs), codebooks replicated, no collective"
 
 # algorithmic work per token
 D, C, K, L = 2304, 5, 1024, 8
 BYTES_PER_TOKEN = D * 2 + D * 4 + L * 8                      # bf16 x in, fp32 recon + int64 codes out = 13888
-FLOPS_PER_TOKEN = L * (2 * D * C + 2 * C * K + 2 * C * D + 2 * D)  # 487424
-# codes only: no `out += y`, and the last level needs neither lin_out nor `r -= y`          = 443648
-FLOPS_PER_TOKEN_CODES = L * (2 * D * C + 2 * C * K) + (L - 1) * (2 * C * D + D)
-PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PEAK_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector) peak
+BYTES_PER_TOKEN_CODES = D * 2 + L * 8                        # 4672
+FLOPS_PER_TOKEN = L * (2 * D * C + 2 * C * K + 2 * C * D + 2 * D)  # 487424, SURVEY 8(d)
+# codes only on the exact arm: no `out += y`, and the last level needs neither lin_out nor `r -= y`     = 443648
+FLOPS_PER_TOKEN_CODES_EXACT = L * (2 * D * C + 2 * C * K) + (L - 1) * (2 * C * D + D)
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.3 TB/s is achievable)
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 (vector = fp32 MFMA) peak
+PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# matrix-core arm: bf16 MFMA flops actually issued per token (every fp32 operand as 3 bf16 pieces, 6 kept products per
+# component in the cosine and reconstruction contractions)
+GRAM_MFMA_FLOPS_PER_TOKEN = 2 * D * 48 * 3 + L * 2 * K * 32 + 2 * D * 256
+
+KERNEL_SOURCES = ["gram.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
 
 
-def synth_batch(n_tokens, device, seed):
+def sources_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "rqae_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def synth_batch(torch, n_tokens, device, seed):
     """Gemma-like residual rows generated ON DEVICE (no H2D in the bench): N(0,1) x heavy-tailed
     channel scale, 4 massive channels, RMS-normalised, x (1+w); rounded to bf16."""
     g = torch.Generator(device=device)
@@ -73,7 +89,33 @@ def cpu_baseline(w, target_seconds=12.0):
             break
     return {"value": n * reps / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"{reps} x {n} tokens of the same workload (bf16-rounded synthetic rows, d=2304 K=1024 depth=8, "
-                      f"codes + reconstruction), oracle/rqae_oracle.c with {threads} OpenMP threads, {dt:.1f} s"}
+                      f"codes + reconstruction), oracle/rqae_oracle.c (C restatement, {threads} OpenMP threads, {dt:.1f} s); "
+                      "the reference's own torch-CPU path ran ~40x slower than this port in the survey container "
+                      "(BASELINE.md section 2: 4.3 k tok/s on 8 threads)"}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 outside a launcher: one child process per GPU.  This parent never touches a GPU (no HIP call, no
+    torch.cuda call) and never execs: it starts the ranks, relays rank 0's JSON line and exits with the worst code."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RQAE_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for ln in out.splitlines():   # ONE JSON line on stdout; anything else a library printed there goes to stderr
+        print(ln, file=sys.stdout if ln.lstrip().startswith("{") else sys.stderr, flush=True)
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -81,37 +123,65 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--tokens", type=int, default=262144, help="tokens per GPU per step")
+    ap.add_argument("--tokens", type=int, default=0, help="tokens per GPU per step (default: 262144 at N=1, 524288 at N>1)")
+    ap.add_argument("--arm", choices=["gram", "exact", "auto"], default="gram",
+                    help="gram = matrix-core arm (Tier-2 parity, the fast path); exact = canonical fp32 order (bit-exact)")
     ap.add_argument("--codes-only", action="store_true", help="time RQAE.encode (no reconstruction written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub", action="store_true", help="CPU/gloo rehearsal of the multi-rank orchestration (tests only)")
     args = ap.parse_args()
+
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    tokens = args.tokens or (262144 if world == 1 else 524288)
     dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # one rank per GPU over RCCL
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif args.gpus > 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
+        if args.stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from rqae_amd import sharding
+
+    if args.stub:
+        # rehearsal of everything around the kernel: rendezvous, barrier-bracketed timing, MAX over ranks, one JSON line
+        def step():
+            time.sleep(0.002 * (rank + 1))
+
+        elapsed = sharding.timed_steps(step, args.steps, args.warmup, dist.barrier if dist else (lambda: None))
+        elapsed = sharding.max_over_ranks(elapsed, dist, None)
+        if rank == 0:
+            print(json.dumps({"metric": "stub", "value": sharding.aggregate_throughput(tokens, world, args.steps, elapsed),
+                              "unit": "tokens/s", "n_gpus": world, "world_size_seen": dist.get_world_size() if dist else 1,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "config": {"tokens_per_gpu_per_step": tokens}}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-
     from rqae_amd import RQAE, _native, synth
 
     w = synth.weights(1234, CFG["dim"], CFG["codebook_dim"], CFG["num_quantizers"], CFG["codebook_size"])
-    model = RQAE(**CFG).eval()
+    model = RQAE(**CFG, arm=args.arm).eval()
     model.load_state_dict(synth.state_dict_from_weights(w), strict=True)
     model = model.to(device)
-    x = synth_batch(args.tokens, device, seed=1000 + rank).view(1, args.tokens, CFG["dim"])
+    x = synth_batch(torch, tokens, device, seed=1000 + rank).view(1, tokens, CFG["dim"])
     fn = model.encode if args.codes_only else model.forward
-
-    from rqae_amd import sharding
+    gram = model._use_gram(tokens, L)
 
     def barrier():
         if dist is not None:
@@ -122,7 +192,7 @@ def main():
 
     def step():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()              # same stream the kernel is launched on (torch's current stream)
+        a.record()              # same stream the kernels are launched on (torch's current stream)
         fn(x)
         b.record()
         evs.append((a, b))
@@ -130,37 +200,66 @@ def main():
     with torch.inference_mode():
         elapsed = sharding.timed_steps(step, args.steps, args.warmup, barrier)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[args.warmup:]]))
+    per_rank = [elapsed]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(v.item()) for v in allt]
     elapsed = sharding.max_over_ranks(elapsed, dist, device)
 
     if rank == 0:
-        value = sharding.aggregate_throughput(args.tokens, world, args.steps, elapsed)
-        bytes_tok = (D * 2 + L * 8) if args.codes_only else BYTES_PER_TOKEN
-        tok_per_s_kernel = args.tokens / (kern_ms * 1e-3)
-        flops_tok = FLOPS_PER_TOKEN_CODES if args.codes_only else FLOPS_PER_TOKEN
-        tflops = tok_per_s_kernel * flops_tok / 1e12
+        value = sharding.aggregate_throughput(tokens, world, args.steps, elapsed)
+        bytes_tok = BYTES_PER_TOKEN_CODES if args.codes_only else BYTES_PER_TOKEN
+        tok_per_s_kernel = tokens / (kern_ms * 1e-3)
         gbs = tok_per_s_kernel * bytes_tok / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath) and not args.codes_only:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("tokens") == args.tokens:
-                    traffic = tj["hbm_bytes_per_launch"]
+                # measured by tools/pmc.py for THIS build and THIS launch shape, or not reported
+                if tj.get("tokens") == tokens and tj.get("arm") == ("gram" if gram else "exact") and tj.get("sources_sha256_16") == sources_hash():
+                    traffic = tj["hbm_bytes_per_step"]
             except Exception:
                 traffic = None
+        if gram:
+            roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    "traffic": traffic, "launch": "one forward = 3 kernels back to back on one stream (projection, level chain, "
+                    "reconstruction)", "launch_ms": kern_ms, "bytes_per_token": bytes_tok,
+                    "mfma_bf16_TFLOPs": tok_per_s_kernel * GRAM_MFMA_FLOPS_PER_TOKEN / 1e12,
+                    "mfma_bf16_frac": tok_per_s_kernel * GRAM_MFMA_FLOPS_PER_TOKEN / 1e12 / PEAK_BF16_TFLOPS,
+                    "algorithmic_fp32_TFLOPs": tok_per_s_kernel * FLOPS_PER_TOKEN / 1e12}
+            try:
+                with torch.inference_mode():
+                    ph = [_native.encode_gram_phases(model.gram_packed_weights(), model._dims(), x.view(tokens, -1), L,
+                                                     want_recon=not args.codes_only) for _ in range(5)]
+                roof["kernel_ms"] = dict(zip(["project", "levels", "reconstruct"], [float(np.median(v)) for v in zip(*ph)]))
+            except Exception as e:  # measurement extra only
+                roof["kernel_ms"] = f"unavailable: {e}"
+        else:
+            flops_tok = FLOPS_PER_TOKEN_CODES_EXACT if args.codes_only else FLOPS_PER_TOKEN
+            tflops = tok_per_s_kernel * flops_tok / 1e12
+            roof = {"bound": "fp32-valu", "achieved": tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / PEAK_F32_TFLOPS, "traffic": traffic, "launch_ms": kern_ms, "flops_per_token": flops_tok,
+                    "flops_per_token_survey_8d": FLOPS_PER_TOKEN,
+                    "frac_survey_8d": tok_per_s_kernel * FLOPS_PER_TOKEN / 1e12 / PEAK_F32_TFLOPS,
+                    "hbm_achieved_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "bytes_per_token": bytes_tok}
         line = {
             "metric": "tokens encoded/sec, d=2304, K=1024, depth=8",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "tokens_per_gpu_per_step": args.tokens,
+            "config": {"workload": WORKLOAD_1 if world == 1 else WORKLOAD_N, "tokens_per_gpu_per_step": tokens,
                        "outputs": "codes int64" + ("" if args.codes_only else " + reconstruction fp32"),
                        "sharding": f"token-sharded x{world}, weights replicated, no collective",
-                       "kernel": _native.kernel_info(D, C, K, L)},
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_F32_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "flops_per_token": flops_tok,
-                         "hbm_achieved_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "bytes_per_token": bytes_tok},
+                       "world_size_seen": dist.get_world_size() if dist is not None else 1,
+                       "per_rank_seconds": per_rank,
+                       "arm": ("gram: all-levels projection + c-space level chain + reconstruction on v_mfma_f32_16x16x32_bf16, "
+                               "fp32 operands as 3 exact bf16 pieces, fp32 accumulate (Tier-2 parity: codes equal wherever the "
+                               "top-1/top-2 margin >= 1e-5, reconstruction <= 1e-5 rel)") if gram
+                       else "exact: canonical fp32 order, bit-equal to the CPU oracle; " + _native.kernel_info(D, C, K, L)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)

@@ -184,6 +184,9 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
  *                                [groups][tokens][16] fp32 and the reconstruction operand rows [k-steps][tokens][32]
  *                                bf16 of at most 131072 tokens at a time (longer batches run in passes)
  *   rqae_hip_encode_gram         x, q_out (or NULL), workspace 16-byte aligned; indices int64 [n_tokens][levels]
+ *   rqae_hip_encode_gram_phases  the same call with HIP events between its three kernels (measurement only: it
+ *                                synchronises the stream); phase_ms[3] = projection, level chain, reconstruction of the
+ *                                last pass, in milliseconds
  */
 int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared);
 size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared);
@@ -192,6 +195,9 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
 size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels);
 int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
                          int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream);
+int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x,
+                                int x_dtype, int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,
+                                void *stream, float *phase_ms);
 
 /* Human-readable name of the encode kernel variant chosen for a shape. */
 int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);

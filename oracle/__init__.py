@@ -6,6 +6,7 @@ this package.  rqae_amd/ (the product) never does.
 from .oracle import (  # noqa: F401
     build,
     forward,
+    adjudicate,
     decode,
     quantize,
     max_threads,

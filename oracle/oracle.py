@@ -40,6 +40,8 @@ def _load():
         lib.rqae_oracle_decode.argtypes = [ip, i64, i, i, i, i, i, fp, fp, fp, bp, fp, i]
         lib.rqae_oracle_decode.restype = i
         lib.rqae_oracle_max_threads.restype = i
+        lib.rqae_oracle_adjudicate.argtypes = [fp, i64, i, i, i, i, i, fp, fp, fp, fp, fp, ip, ctypes.POINTER(ctypes.c_double), ip, i]
+        lib.rqae_oracle_adjudicate.restype = None
         dp = ctypes.POINTER(ctypes.c_double)
         lib.rqae_oracle_codebook_sims.argtypes = [fp, i, i, fp]
         lib.rqae_oracle_codebook_sims.restype = None
@@ -91,6 +93,32 @@ def forward(x, w, max_layers=None, want_margins=False, want_recon=True, threads=
     if want_margins:
         out = out + (mg.reshape(lead + (levels,)),)
     return out
+
+
+def adjudicate(x, w, codes, threads=0):
+    """SURVEY 8(c) Tier-2 adjudicator: RQAE.forward's level loop in float64 ALONG the given code path.
+
+    Returns (gap[..., levels] float64, argmax[..., levels] int64): gap = the double-precision cosine of the best row
+    minus that of the given code at that level (0 = the code is the double-precision argmax or a copy of it)."""
+    lib = _load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    codes = np.ascontiguousarray(codes, dtype=np.int64)
+    lead, d = x.shape[:-1], x.shape[-1]
+    levels = codes.shape[-1]
+    L, c, dd = w["w_in"].shape
+    K = w["codebook"].shape[1]
+    assert dd == d and codes.shape[:-1] == lead and levels <= L
+    n = int(np.prod(lead)) if lead else 1
+    xa, xp = _f(x.reshape(n, d))
+    wi, wip = _f(w["w_in"]); bi, bip = _f(w["b_in"]); cb, cbp = _f(w["codebook"])
+    wo, wop = _f(w["w_out"]); bo, bop = _f(w["b_out"])
+    gap = np.empty((n, levels), np.float64)
+    am = np.empty((n, levels), np.int64)
+    lib.rqae_oracle_adjudicate(xp, n, d, c, K, L, levels, wip, bip, cbp, wop, bop,
+                               codes.reshape(n, levels).ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                               gap.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                               am.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), int(threads))
+    return gap.reshape(lead + (levels,)), am.reshape(lead + (levels,))
 
 
 def quantize(p, codebook_l, want_margins=False, threads=0):

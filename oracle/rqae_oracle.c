@@ -108,10 +108,17 @@ static int64_t nearest_row(const float *xn, const float *cbT, int c, int K, floa
     for (int n = 1; n < K; ++n)
         if (beats(sims[n], best)) { best = sims[n]; bidx = n; }
     if (margin_out) {
-        /* top-1 minus the best value strictly below it (duplicates excluded) */
+        /* top-1 minus the best similarity among rows that point in a different direction: rows that are bit-for-bit
+         * copies of the winner (the FSQ lattices hold such duplicates) are excluded, every other row counts --
+         * two distinct rows whose fp32 similarities are equal give margin 0 (the tie that torch.argmax breaks by index).
+         * This is the margin of SURVEY 8(c)'s Tier-2 policy. */
         float second = -INFINITY;
-        for (int n = 0; n < K; ++n)
-            if (sims[n] < best && sims[n] > second) second = sims[n];
+        for (int n = 0; n < K; ++n) {
+            if (n == bidx) continue;
+            int same = 1;
+            for (int k = 0; k < c && same; ++k) same = cbT[(size_t)k * K + n] == cbT[(size_t)k * K + bidx];
+            if (!same && sims[n] > second) second = sims[n];
+        }
         *margin_out = isnan(best) ? NAN : best - second;
     }
     return bidx;
@@ -200,7 +207,7 @@ static void lin_in_canonical(const packed_t *p, int l, const float *r, float *q)
  * RQAE.forward (rqae/model.py:199-230) on x[n_tokens][d] fp32.
  *   q_out   [n_tokens][d] fp32 or NULL
  *   indices [n_tokens][levels] int64
- *   margins [n_tokens][levels] fp32 or NULL (top-1 minus next distinct value)
+ *   margins [n_tokens][levels] fp32 or NULL (top-1 minus the best row that is not a copy of the winner)
  * levels = min(L, max_layers) is passed by the caller.
  */
 void rqae_oracle_forward(const float *x, int64_t n_tokens, int d, int c, int K, int L, int levels,
@@ -265,6 +272,74 @@ void rqae_oracle_forward(const float *x, int64_t n_tokens, int d, int c, int K, 
         free(r); free(out); free(y); free(sims); free(q);
     }
     unpack(&p);
+}
+
+/*
+ * Adjudicator for SURVEY 8(c)'s Tier-2 policy: the level loop of RQAE.forward (rqae/model.py:199-230) in DOUBLE
+ * precision along a GIVEN code path.  For token n and level l the residual is advanced with codes[n][l] (whatever
+ * produced them), and the level reports
+ *   gap[n][l]    = max_k cos(q_l, codebook[l][k]) - cos(q_l, codebook[l][codes[n][l]])   (>= 0; 0 = the code is the
+ *                  double-precision argmax or a copy of it)
+ *   argmax[n][l] = lowest index attaining the double-precision maximum
+ * so a code path is "an argmax path up to rounding" exactly when every gap is at rounding level.  A zero or
+ * non-finite projection reports gap 0 for code 0 (torch.argmax over NaNs) and +inf otherwise.
+ */
+void rqae_oracle_adjudicate(const float *x, int64_t n_tokens, int d, int c, int K, int L, int levels,
+                            const float *w_in, const float *b_in, const float *cb, const float *w_out,
+                            const float *b_out, const int64_t *codes, double *gap, int64_t *argmax, int n_threads)
+{
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    (void)L;
+#pragma omp parallel
+    {
+        double *r = (double *)malloc(sizeof(double) * d);
+        double *q = (double *)malloc(sizeof(double) * 2 * c);
+        double *cv = q + c;
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < n_tokens; ++n) {
+            for (int e = 0; e < d; ++e) r[e] = (double)x[n * d + e];
+            for (int l = 0; l < levels; ++l) {
+                double n2 = 0.0;
+                for (int j = 0; j < c; ++j) {
+                    const float *w = w_in + ((size_t)l * c + j) * d;
+                    double s = 0.0;
+                    for (int e = 0; e < d; ++e) s += (double)w[e] * r[e];
+                    q[j] = s + (double)b_in[(size_t)l * c + j];
+                    n2 += q[j] * q[j];
+                }
+                const double nrm = sqrt(n2);
+                const int64_t code = codes[n * levels + l];
+                const float *cbl = cb + (size_t)l * K * c;
+                if (!(nrm > 0.0) || !isfinite(nrm)) {
+                    gap[n * levels + l] = code == 0 ? 0.0 : INFINITY;
+                    argmax[n * levels + l] = 0;
+                } else {
+                    double best = -INFINITY, mine = 0.0;
+                    int64_t bi = 0;
+                    for (int k = 0; k < K; ++k) {
+                        double s = 0.0;
+                        for (int j = 0; j < c; ++j) s += (double)cbl[(size_t)k * c + j] * q[j];
+                        s /= nrm;
+                        if (s > best) { best = s; bi = k; }
+                        if (k == code) mine = s;
+                    }
+                    gap[n * levels + l] = best - mine;
+                    argmax[n * levels + l] = bi;
+                }
+                const float *row = cbl + (size_t)code * c;
+                for (int j = 0; j < c; ++j) cv[j] = q[j] + ((double)row[j] - q[j]);
+                for (int e = 0; e < d; ++e) {
+                    const float *w = w_out + ((size_t)l * d + e) * c;
+                    double y = (double)b_out[(size_t)l * d + e];
+                    for (int j = 0; j < c; ++j) y += (double)w[j] * cv[j];
+                    r[e] -= y;
+                }
+            }
+        }
+        free(r); free(q);
+    }
 }
 
 /*

@@ -44,6 +44,7 @@ SYMBOLS = (
     "rqae_hip_gram_pack",
     "rqae_hip_gram_workspace_bytes",
     "rqae_hip_encode_gram",
+    "rqae_hip_encode_gram_phases",
 )
 
 _lib = None
@@ -111,6 +112,8 @@ def lib():
     L.rqae_hip_gram_workspace_bytes.restype = sz
     L.rqae_hip_encode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, vp]
     L.rqae_hip_encode_gram.restype = i
+    L.rqae_hip_encode_gram_phases.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.rqae_hip_encode_gram_phases.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"librqae_hip.so ABI {L.rqae_hip_abi_version()} != expected {ABI_VERSION}; rebuild")
@@ -239,6 +242,22 @@ def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels:
                                         idx.data_ptr(), workspace.data_ptr(), _stream(x2d.device))
     _check(rc, "rqae_hip_encode_gram")
     return q, idx
+
+
+def encode_gram_phases(gpacked, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True):
+    """Measurement only: one encode_gram call timed per kernel -> [ms projection, ms level chain, ms reconstruction]."""
+    d, c, K, L_ = dims
+    n = x2d.shape[0]
+    q = torch.empty((n, d), dtype=torch.float32, device=x2d.device) if want_recon else None
+    idx = torch.empty((n, levels), dtype=torch.int64, device=x2d.device)
+    ws = torch.empty(gram_workspace_bytes(dims, n, levels), dtype=torch.uint8, device=x2d.device)
+    ms = (ctypes.c_float * 3)()
+    with torch.cuda.device(x2d.device):
+        rc = lib().rqae_hip_encode_gram_phases(gpacked.data_ptr(), d, c, K, L_, 1, x2d.data_ptr(), _X_DTYPES[x2d.dtype], n,
+                                               levels, q.data_ptr() if want_recon else None, idx.data_ptr(), ws.data_ptr(),
+                                               _stream(x2d.device), ms)
+    _check(rc, "rqae_hip_encode_gram_phases")
+    return [float(v) for v in ms]
 
 
 def quantize(p2d: torch.Tensor, codebook_l: torch.Tensor):

@@ -1085,8 +1085,13 @@ size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_token
     return ws_bytes(make_geom(d, c, K, L, 1), n_tokens > 0 ? n_tokens : 1, levels);
 }
 
-int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
-                         int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream)
+}  // extern "C"
+
+namespace {
+// ev: NULL, or 4 events recorded before the projection, between the kernels and after the reconstruction of the LAST
+// chunk (rqae_hip_encode_gram_phases)
+int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
+                     int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream, hipEvent_t *ev)
 {
     if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared)) return gfail("encode_gram: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
     if (!packed || !x || !indices || !workspace) return gfail("encode_gram: null pointer");
@@ -1112,6 +1117,8 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
 
     for (long long t0 = 0; t0 < n_tokens; t0 += chunk) {
         const long long nt = n_tokens - t0 < chunk ? n_tokens - t0 : chunk;
+        const bool mark = ev && t0 + chunk >= n_tokens;
+        if (mark) G_TRY(hipEventRecord(ev[0], s));
         // ---- A
         ProjParams pa;
         pa.x = static_cast<const char *>(x) + (size_t)t0 * d * xs;
@@ -1131,6 +1138,7 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
             else rc = go(gram_project_kernel<RQAE_X_F32>);
             if (rc) return rc;
         }
+        if (mark) G_TRY(hipEventRecord(ev[1], s));
         // ---- B
         LevParams pb;
         pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
@@ -1152,6 +1160,7 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
                                      : (multi ? go(gram_levels_kernel<5, B_NW, true>) : go(gram_levels_kernel<5, B_NW, false>));
             if (rc) return rc;
         }
+        if (mark) G_TRY(hipEventRecord(ev[2], s));
         // ---- C
         if (q_out) {
             RecParams pc;
@@ -1192,8 +1201,39 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
 #undef REC
             if (rc) return rc;
         }
+        if (mark) G_TRY(hipEventRecord(ev[3], s));
     }
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
+                         int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream)
+{
+    return encode_gram_impl(packed, d, c, K, L, codebook_shared, x, x_dtype, n_tokens, levels, q_out, indices, workspace, stream,
+                            nullptr);
+}
+
+int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
+                                int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream,
+                                float *phase_ms)
+{
+    if (!phase_ms) return gfail("encode_gram_phases: phase_ms is NULL");
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i) G_TRY(hipEventCreate(&ev[i]));
+    int rc = encode_gram_impl(packed, d, c, K, L, codebook_shared, x, x_dtype, n_tokens, levels, q_out, indices, workspace, stream, ev);
+    if (!rc && n_tokens > 0) {
+        hipError_t e = hipEventSynchronize(ev[3]);
+        if (e != hipSuccess) rc = gfail("encode_gram_phases: %s", hipGetErrorString(e));
+        for (int i = 0; i < 3 && !rc; ++i)
+            if (hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = gfail("encode_gram_phases: event timing failed");
+    } else if (!rc) {
+        phase_ms[0] = phase_ms[1] = phase_ms[2] = 0.0f;
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 }  // extern "C"

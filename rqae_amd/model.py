@@ -49,6 +49,8 @@ def _fsq_grid(codebook_dim: int, codebook_size: int, unit_rows: bool) -> torch.T
 class RQAE(nn.Module):
     """Residual-quantisation autoencoder; see module docstring for the mapping."""
 
+    GRAM_MIN_TOKENS = 16384   # arm="auto": below this the exact arm's single launch wins
+
     PRETRAINED = {
         "google/gemma-2-2b": "harish-kamath/rqae/gemma-2-2b",
         "rqae-rqae-round_fsq-cbd4-cbs5-nq1024": "harish-kamath/rqae/gemma-2-2b",
@@ -75,6 +77,18 @@ class RQAE(nn.Module):
         self._dim = dim
         self._packed = None
         self._packed_key = None
+        self._gram = None            # (key, packed block, shared flag) of the matrix-core arm
+        self._gram_ws = None
+        # which encode arm forward()/encode() take (not a reference argument; rides in **kwargs so the reference's
+        # constructor signature stays as it is):
+        #   "exact" (default) -- rqae_hip_encode: the canonical fp32 order, bit-equal to the CPU oracle
+        #   "gram"            -- rqae_hip_encode_gram: all-levels projection + c-space level chain + reconstruction on the
+        #                        bf16 matrix cores (bf16x3 operand split), SURVEY 8(c) Tier-2 parity: same codes wherever
+        #                        the top-1/top-2 margin is >= 1e-5, reconstruction within 1e-5 relative
+        #   "auto"            -- gram for batches of >= GRAM_MIN_TOKENS tokens on shapes it serves, else exact
+        self.arm = kwargs.pop("arm", os.environ.get("RQAE_HIP_ARM", "exact"))
+        if self.arm not in ("exact", "gram", "auto"):
+            raise ValueError(f"unknown encode arm {self.arm!r}")
 
         self.normalize_codebooks()
         if is_fsq:
@@ -112,11 +126,14 @@ class RQAE(nn.Module):
     # ------------------------------------------------------- packed-weight cache
     def _apply(self, fn, *args, **kwargs):
         self._packed = None  # .to()/.cuda()/.float() move or retype the parameters
+        self._gram = None
+        self._gram_ws = None
         self._drop_metadata_cache()
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
         self._packed = None
+        self._gram = None
         self._drop_metadata_cache()
         return super().load_state_dict(*args, **kwargs)
 
@@ -130,35 +147,39 @@ class RQAE(nn.Module):
         state = self.__dict__.copy()
         state["_packed"] = None
         state["_packed_key"] = None
+        state["_gram"] = None
+        state["_gram_ws"] = None
+        state.pop("_param_list", None)
         return state
 
     def _dims(self):
         return (self._dim, self.codebook_dim, self.codebook.shape[1], self.num_quantizers)
 
     def _weights_key(self):
-        """Cheap fingerprint of the parameters the packed block was built from.
-
-        In eval mode (the only mode the hot path serves) parameters change through
-        ``load_state_dict`` / ``.to()`` -- both drop the cache explicitly -- so the fingerprint is the
-        device, two data pointers and the version counters of the first and last level: O(1) per call
-        (the pretrained model has 4096 parameter tensors; walking them costs more than a 512-token
-        encode).  In training mode every tensor's version counter is summed.  ``invalidate_packed()``
-        forces a rebuild after any other in-place edit.
-        """
-        first, last = self.layers[0], self.layers[-1]
-        ver = self.codebook._version
-        if self.training:
+        """Fingerprint of the parameters the packed blocks were built from: device, mode, and for EVERY parameter
+        tensor its storage pointer and version counter (the reference reads the weights live at every call,
+        rqae/model.py:199-230, so an in-place edit of any level must be seen).  The tensors are walked through a
+        cached flat list -- ~40 us for the 4097 tensors of the pretrained shape, far below a 512-token encode.
+        A ``.data`` write that keeps the storage (``p.data.copy_``) bumps no counter: call ``invalidate_packed()``
+        after one."""
+        plist = self.__dict__.get("_param_list")
+        if plist is None or len(plist) != 4 * len(self.layers) + 1:
+            plist = [self.codebook]
             for lin_in, lin_out in self.layers:
-                ver += lin_in.weight._version + lin_in.bias._version + lin_out.weight._version + lin_out.bias._version
-        else:
-            for lin in (first[0], first[1], last[0], last[1]):
-                ver += lin.weight._version + lin.bias._version
-        return (self.codebook.device, self.training, self.codebook.data_ptr(), first[0].weight.data_ptr(),
-                last[1].weight.data_ptr(), ver)
+                plist += [lin_in.weight, lin_in.bias, lin_out.weight, lin_out.bias]
+            self.__dict__["_param_list"] = plist
+        ver = 0
+        ptr = 0
+        for t in plist:
+            ver += t._version
+            ptr ^= t.data_ptr()
+        return (self.codebook.device, self.training, ptr, ver, len(plist))
 
     def invalidate_packed(self):
-        """Drop the packed parameter block (call after editing parameters in place in eval mode)."""
+        """Drop the packed parameter blocks (call after a ``.data`` write that the version counters cannot see)."""
         self._packed = None
+        self._gram = None
+        self.__dict__.pop("_param_list", None)
 
     def _stacked(self):
         w_in = torch.stack([l[0].weight for l in self.layers]).float().contiguous()
@@ -210,6 +231,45 @@ class RQAE(nn.Module):
                 used[l] = self.codebook.data[l]
             self.__dict__["_codebook_used"] = used[:levels].clone()
             return self._pack(used)
+
+    # ------------------------------------------------------------ matrix-core arm
+    def _use_gram(self, n_tokens: int, levels: int) -> bool:
+        if self.arm == "exact" or self.quantization_method not in _FSQ_METHODS:
+            return False
+        ok = _native.gram_supported(self._dims(), True)
+        if self.arm == "gram":
+            if not ok:
+                raise RuntimeError(f"rqae_amd: arm='gram' does not serve shape (d, c, K, L) = {self._dims()} "
+                                   "(include/rqae_hip.h: rqae_hip_gram_supported); use arm='exact' or 'auto'")
+            return True
+        return ok and n_tokens >= self.GRAM_MIN_TOKENS
+
+    def gram_packed_weights(self) -> torch.Tensor:
+        """The matrix-core arm's own parameter block (include/rqae_hip.h: rqae_hip_gram_pack), cached like
+        ``packed_weights``."""
+        key = self._weights_key()
+        if self._gram is None or self._gram[0] != key:
+            dev = self.codebook.device
+            if dev.type != "cuda":
+                raise RuntimeError(f"rqae_amd: module parameters are on {dev}; the RQAE hot path runs on a ROCm "
+                                   "device only (no CPU fallback). Call .to('cuda') first.")
+            with torch.no_grad():
+                w_in, b_in, w_out, b_out = self._stacked()
+                cb = self.codebook.detach().float().contiguous()
+                if not torch.isfinite(cb).all():
+                    raise RuntimeError("rqae_amd: codebook contains non-finite values")
+                if not bool((cb == cb[:1]).all()):
+                    raise RuntimeError("rqae_amd: the matrix-core arm needs one codebook shared by all levels")
+                self._gram = (key, _native.gram_pack(w_in, b_in, cb, w_out, b_out, True))
+        return self._gram[1]
+
+    def _encode_gram(self, x2d, levels, want_recon):
+        need = _native.gram_workspace_bytes(self._dims(), x2d.shape[0], levels)
+        ws = self._gram_ws
+        if ws is None or ws.device != x2d.device or ws.numel() < need:
+            ws = self._gram_ws = torch.empty(need, dtype=torch.uint8, device=x2d.device)
+        return _native.encode_gram(self.gram_packed_weights(), self._dims(), True, x2d, levels,
+                                   want_recon=want_recon, workspace=ws)
 
     # ------------------------------------------------------------- small mirrors
     def update_codebook_counts(self, indices):
@@ -294,18 +354,47 @@ class RQAE(nn.Module):
         return temperature < 1e-7 or not self.training
 
     def gumbel_sample(self, cos_sim, temperature=0.0):
-        """argmax over the last dim (rqae/model.py:180-185).  The stochastic
-        gumbel-softmax branch (training with temperature >= 1e-7) is a training
-        feature outside the encode path and is not provided."""
+        """Index per row of cos_sim (rqae/model.py:180-185): argmax in eval mode or at temperature < 1e-7,
+        otherwise the hard gumbel-softmax sample the reference draws while training."""
         if self._deterministic(temperature):
             return cos_sim.argmax(dim=-1)
-        raise NotImplementedError("rqae_amd: gumbel sampling (training, temperature>0) is out of scope")
+        return F.gumbel_softmax(cos_sim, tau=temperature, hard=True).argmax(dim=-1)
+
+    def _needs_autograd(self, x) -> bool:
+        """True while training with gradients flowing: the HIP kernels are inference kernels (no autograd graph), so
+        such a call is served by the torch ops of ``_forward_training`` -- the training-time branch of the reference
+        (straight-through estimator, optional gumbel sampling), never the inference hot path."""
+        return self.training and torch.is_grad_enabled() and (
+            x.requires_grad or any(p.requires_grad for p in self.layers.parameters()))
+
+    def _quantize_training(self, x, layer_idx, temperature):
+        unit = x / x.norm(dim=-1, keepdim=True)
+        rows = self.codebook[layer_idx]
+        picked = self.gumbel_sample(unit @ rows.T, temperature=temperature)
+        return rows[picked], picked
+
+    def _forward_training(self, x, levels, temperature):
+        """Training-time forward with torch ops (autograd + stochastic sampling; rqae/model.py:199-230)."""
+        residual, total, picked_all = x, 0, []
+        for level in range(levels):
+            lin_in, lin_out = self.layers[level]
+            proj = lin_in(residual)
+            self.normalize_codebooks()
+            rows, picked = self._quantize_training(proj, level, temperature)
+            picked_all.append(picked)
+            step = lin_out(proj + (rows - proj).detach())       # straight-through estimator
+            residual = residual - step.detach()
+            total = total + step
+        codes = torch.stack(picked_all).permute(1, 2, 0)
+        self.update_codebook_counts(codes)
+        return total, codes
 
     def quantize_gumbel(self, x, layer_idx, temperature=0.0):
         """x[..., c] -> (nearest unit codebook row by cosine, its index) for one level
-        (rqae/model.py:187-193); one launch of the HIP quantize kernel."""
-        if not self._deterministic(temperature):
-            raise NotImplementedError("rqae_amd: gumbel sampling (training, temperature>0) is out of scope")
+        (rqae/model.py:187-193); one launch of the HIP quantize kernel (torch ops while training with
+        temperature >= 1e-7 or gradients)."""
+        if not self._deterministic(temperature) or self._needs_autograd(x):
+            return self._quantize_training(x, layer_idx, temperature)
         lead = x.shape[:-1]
         p = x.reshape(-1, x.shape[-1]).float().contiguous()
         cv, idx = _native.quantize(p, self.codebook[layer_idx].detach().float().contiguous())
@@ -320,10 +409,10 @@ class RQAE(nn.Module):
 
         Same values as the reference level loop (rqae/model.py:199-230); levels =
         min(num_quantizers, max_layers).  x may be fp32 (reference), bf16 or fp16
-        (widened exactly to fp32 on load).  One kernel launch.
+        (widened exactly to fp32 on load).  One launch of the exact arm, or the three kernels of the matrix-core
+        arm when ``self.arm`` selects it (see __init__).  While training with gradients or temperature >= 1e-7 the
+        call is served by torch ops (``_forward_training``): the kernels are inference kernels.
         """
-        if not self._deterministic(temperature):
-            raise NotImplementedError("rqae_amd: gumbel sampling (training, temperature>0) is out of scope")
         if x.dim() != 3:
             raise RuntimeError(f"RQAE.forward expects x of shape (B, S, dim), got {tuple(x.shape)}")
         levels = self.num_quantizers if max_layers >= self.num_quantizers else int(math.ceil(max_layers))
@@ -332,8 +421,13 @@ class RQAE(nn.Module):
         B, S, d = x.shape
         if d != self._dim:
             raise RuntimeError(f"RQAE.forward: last dim {d} != model dim {self._dim}")
-        packed = self._packed_for_encode(levels)
-        q, idx = _native.encode(packed, self._dims(), x.reshape(B * S, d).contiguous(), levels)
+        if not self._deterministic(temperature) or self._needs_autograd(x):
+            return self._forward_training(x, levels, temperature)
+        x2d = x.reshape(B * S, d).contiguous()
+        if self._use_gram(B * S, levels):
+            q, idx = self._encode_gram(x2d, levels, True)
+        else:
+            q, idx = _native.encode(self._packed_for_encode(levels), self._dims(), x2d, levels)
         idx = idx.view(B, S, levels)
         self.update_codebook_counts(idx)
         return q.view(B, S, d), idx
@@ -346,9 +440,13 @@ class RQAE(nn.Module):
         if levels <= 0:
             raise RuntimeError("RQAE.encode: max_layers leaves no quantizer to run")
         B, S, d = x.shape
-        packed = self._packed_for_encode(levels)
-        _, idx = _native.encode(packed, self._dims(), x.reshape(B * S, d).contiguous(), levels,
-                                want_recon=False)
+        if d != self._dim:
+            raise RuntimeError(f"RQAE.encode: last dim {d} != model dim {self._dim}")
+        x2d = x.reshape(B * S, d).contiguous()
+        if self._use_gram(B * S, levels):
+            _, idx = self._encode_gram(x2d, levels, False)
+        else:
+            _, idx = _native.encode(self._packed_for_encode(levels), self._dims(), x2d, levels, want_recon=False)
         return idx.view(B, S, levels)
 
     def indices_to_codebook_values(self, indices):
@@ -444,7 +542,7 @@ class RQAE(nn.Module):
                     or hs_llm.dtype not in (torch.float16, torch.bfloat16, torch.float32)):
                 return generic_hook(module, input, output)   # same values, torch ops around forward()
             if store is not None:
-                store("original", hs_llm.float())
+                store("original", hs_llm.detach().float().clone() if hs_llm.dtype == torch.float32 else hs_llm.detach().float())
             # (small batches run on 4-token workgroups, which only the plain encode kernel has: below 8 tokens per
             #  CU the norm as its own kernel + forward is the faster pair -- 3.06 vs 3.63 ms at 4 x 128 tokens, 1024 levels)
             n_tok = hs_llm.shape[0] * hs_llm.shape[1]

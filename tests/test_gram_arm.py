@@ -1,0 +1,257 @@
+"""GPU: the matrix-core ("gram") arm of RQAE.forward (rqae_hip_encode_gram, csrc/gram.hip) under SURVEY 8(c)'s
+Tier-2 parity policy.
+
+The arm computes the same function as rqae/model.py:199-230 with a different (algebraically equal) order of
+operations on the bf16 matrix cores with exactly split operands, so its results carry fp32-level rounding but not
+the canonical order's bits.  The bar, written out in `check_tier2`:
+
+* codes identical to the oracle's for every token whose smallest per-level top-1/top-2 margin is >= 1e-5
+  (margin = oracle's fp32 cosine of the winner minus the best row that is not a copy of it);
+* every token that differs is listed; at its first differing level the margin is < 1e-5, and along ITS OWN code
+  path every level's code is the float64 argmax up to rounding (oracle.adjudicate: gap < 1e-6) -- i.e. it is what the
+  reference computes when the near-tie falls the other way;
+* reconstruction within 1e-5 (relative to the row's largest magnitude) of the oracle's on tokens with the
+  oracle's codes, and of oracle.decode(own codes) on the listed tokens.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import case_inputs, load_golden
+from rqae_amd import RQAE, _native, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MARGIN = 1e-5      # SURVEY 8(c) Tier 2
+GAP = 1e-6         # float64 cosine gap that still counts as "the argmax up to fp32 rounding"
+RTOL = 1e-5        # north_star: reconstruction within 1e-5 relative
+
+
+def make_model(cfg, w, arm):
+    m = RQAE(**cfg, arm=arm).eval()
+    m.load_state_dict(synth.state_dict_from_weights(w), strict=True)
+    return m.to(DEV)
+
+
+def row_rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float((np.abs(a - b).max(axis=-1) / np.maximum(np.abs(b).max(axis=-1), 1e-30)).max()) if len(a) else 0.0
+
+
+def check_tier2(x, w, q, idx, levels=None, oracle_out=None):
+    """x [n,d] fp32 values the kernel saw, (q, idx) its outputs.  Returns the number of listed (low-margin) tokens."""
+    q_o, idx_o, mg = oracle_out if oracle_out is not None else oracle.forward(x, w, max_layers=levels, want_margins=True)
+    differ = (idx != idx_o).any(axis=1)
+    rows = np.nonzero(differ)[0]
+    # (1) identical wherever the margin allows no doubt
+    safe = np.nanmin(mg, axis=1) >= MARGIN
+    assert not (differ & safe).any(), f"codes differ on tokens with margin >= {MARGIN}: {np.nonzero(differ & safe)[0][:10]}"
+    # (2) the listed tokens: low margin where they part, and an argmax path of their own
+    if len(rows):
+        first = np.argmax(idx[rows] != idx_o[rows], axis=1)
+        assert (mg[rows, first] < MARGIN).all(), (rows, first, mg[rows, first])
+        gap, _ = oracle.adjudicate(x[rows], w, idx[rows])
+        assert gap.max() < GAP, f"listed tokens {rows[:10]} leave the argmax path: gap {gap.max():.3g}"
+    # (3) reconstruction
+    if q is not None:
+        same = ~differ
+        assert row_rel(q[same], q_o[same]) < RTOL
+        if len(rows):
+            assert row_rel(q[rows], oracle.decode(idx[rows], w)) < RTOL
+    return len(rows)
+
+
+def run(m, x, dtype, **kw):
+    n, d = x.shape
+    xt = torch.from_numpy(x).to(DEV).to(dtype).view(1, n, d)
+    with torch.inference_mode():
+        q, idx = m(xt, **kw)
+    torch.cuda.synchronize()
+    assert q.dtype == torch.float32 and idx.dtype == torch.int64 and idx.is_contiguous()
+    return q.cpu().numpy().reshape(n, d), idx.cpu().numpy().reshape(n, -1), xt.float().cpu().numpy().reshape(n, d)
+
+
+@pytest.mark.parametrize("name,dtype", [("fwd_c2", torch.float32), ("fwd_c2_bf16", torch.bfloat16), ("fwd_c2", torch.float16),
+                                        ("fwd_c1", torch.float32), ("fwd_p", torch.float32), ("fwd_c2_max3", torch.float32)])
+def test_gram_fixtures_tier2(name, dtype):
+    """The reference captures (tests/golden) and the oracle on the fixtures' inputs."""
+    g = load_golden(name)
+    cfg, w, x = case_inputs(g)
+    m = make_model(cfg, w, "gram")
+    ml = g["meta"]["max_layers"]
+    kw = {} if ml is None else dict(max_layers=ml)
+    q, idx, xs = run(m, x, dtype, **kw)
+    listed = check_tier2(xs, w, q, idx, levels=ml)
+    if dtype != torch.float16:      # the capture is of the reference on exactly these inputs
+        ref = g["codes"].astype(np.int64)
+        bad = (idx != ref).any(axis=1)
+        assert bad.sum() <= max(listed, 0) + 2, f"{bad.sum()} tokens differ from the reference capture, {listed} listed"
+        ok = ~bad
+        rows = g["rows"][ok[g["rows"]]]
+        sel = np.isin(g["rows"], rows)
+        assert row_rel(q[rows], g["q_rows"][sel]) < RTOL
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 255, 257, 1023, 4097])
+def test_gram_tile_boundaries(n):
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(77, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    x = synth.activations(300 + n, n, cfg["dim"])
+    q, idx, xs = run(m, x, torch.float32)
+    check_tier2(xs, w, q, idx)
+    with torch.inference_mode():
+        only = m.encode(torch.from_numpy(x).to(DEV).view(1, n, -1))
+    assert np.array_equal(only.cpu().numpy().reshape(n, -1), idx)       # codes-only call: same codes
+
+
+def test_gram_empty_batch_and_errors():
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    with torch.inference_mode():
+        q, idx = m(torch.zeros(2, 0, cfg["dim"], device=DEV))
+    assert q.shape == (2, 0, cfg["dim"]) and idx.shape == (2, 0, 8)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, cfg["dim"], device=DEV))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4, cfg["dim"]))
+    # shapes the arm does not serve: 'gram' says so, 'auto' takes the exact arm
+    c4 = synth.CONFIGS["C4"]
+    w4 = synth.weights(2, c4["dim"], c4["codebook_dim"], 2, c4["codebook_size"])
+    big = make_model(dict(c4, num_quantizers=2), w4, "gram")
+    with pytest.raises(RuntimeError, match="does not serve"):
+        big(torch.zeros(1, 4, c4["dim"], device=DEV))
+    auto = make_model(dict(c4, num_quantizers=2), w4, "auto")
+    exact = make_model(dict(c4, num_quantizers=2), w4, "exact")
+    x = torch.from_numpy(synth.activations(9, 64, c4["dim"])).to(DEV).view(1, 64, -1)
+    with torch.inference_mode():
+        assert torch.equal(auto(x)[1], exact(x)[1])
+
+
+def test_gram_nonfinite_and_zero_rows():
+    """Zero / NaN / inf rows take index 0 at the level where the projection is not a finite non-zero vector
+    (torch.argmax over NaNs, rqae/model.py:182,188); neighbours are unaffected."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(5, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    x = synth.activations(11, 200, cfg["dim"])
+    clean = run(m, x, torch.float32)[1]
+    x2 = x.copy()
+    x2[17] = np.nan
+    x2[64, 5] = np.inf
+    x2[130] = 0.0          # zero row: the projection is b_in (finite), nothing special
+    _, idx, _ = run(m, x2, torch.float32)
+    keep = np.ones(200, bool); keep[[17, 64, 130]] = False
+    assert np.array_equal(idx[keep], clean[keep])
+    assert (idx[17] == 0).all() and (idx[64] == 0).all()
+    _, idx_o = oracle.forward(x2[130:131], w)
+    assert np.array_equal(idx[130:131], idx_o)
+
+
+def test_gram_full_size_c2_and_north_star_size():
+    """BASELINE configs[1] (262 144 tokens, bf16 in) and north_star's target size (1 048 576 tokens): the gram arm against
+    the exact arm (itself bit-equal to the oracle: test_hip_parity.py), differing tokens adjudicated by the oracle."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    mg_, me_ = make_model(cfg, w, "gram"), make_model(cfg, w, "exact")
+    for n, seed in ((262144, 5), (1048576, 6)):
+        g = torch.Generator(device=DEV); g.manual_seed(seed)
+        x = torch.empty(n, cfg["dim"], device=DEV, dtype=torch.bfloat16)
+        for s in range(0, n, 65536):
+            z = torch.randn(65536, cfg["dim"], device=DEV, generator=g)
+            x[s:s + 65536] = (z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16)
+        with torch.inference_mode():
+            q, idx = mg_(x.view(1, n, -1))
+            q2, idx2 = mg_(x.view(1, n, -1))
+            assert torch.equal(idx, idx2) and torch.equal(q, q2)                           # deterministic
+            cut = 100003
+            qa, ia = mg_(x[:cut].view(1, -1, cfg["dim"]))
+            assert torch.equal(ia[0], idx[0, :cut]) and torch.equal(qa[0], q[0, :cut])     # tokens independent
+            assert torch.equal(mg_(x.view(1, n, -1), max_layers=3)[1], idx[..., :3])        # prefix property
+            assert torch.equal(mg_.encode(x.view(1, n, -1)), idx)                          # codes-only path
+            assert int(idx.min()) >= 0 and int(idx.max()) < 1024
+            qe, ie = me_(x.view(1, n, -1))
+            bad = (idx[0] != ie[0]).any(dim=1)
+            rows = torch.nonzero(bad).flatten()
+            assert len(rows) <= n // 20000, f"{len(rows)} of {n} tokens differ from the exact arm"
+            same = ~bad
+            scale = qe[0][same].abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+            assert float(((q[0][same] - qe[0][same]).abs() / scale).max()) < RTOL
+            dec = me_.decode(idx)
+            assert float((dec - q).abs().max() / q.abs().max()) < 2e-6                     # decode == reconstruction
+        r = rows.cpu().numpy()
+        sel = np.unique(np.concatenate([r, np.arange(0, n, 4099)]))
+        xs = x[sel].float().cpu().numpy()
+        listed = check_tier2(xs, w, q[0][sel].cpu().numpy(), idx[0][sel].cpu().numpy())
+        assert listed == len(r)
+        print(f"gram arm, {n} tokens: {len(r)} low-margin tokens differ from the exact arm, all adjudicated")
+        del x, q, idx, q2, idx2, qe, ie, dec
+        torch.cuda.empty_cache()
+
+
+def test_gram_deep_shape_and_half_inputs():
+    """The pretrained shape's (c 4, K 625: duplicate rows, a zero row, a ragged last row block) first 16 levels -- two
+    level groups, so later groups' projections are corrected through the workspace -- in all three input types."""
+    cfg = synth.CONFIGS["P"]
+    w = synth.weights(4321, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    x = synth.activations(21, 3000, cfg["dim"])
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        q, idx, xs = run(m, x, dt)
+        check_tier2(xs, w, q, idx)
+    q, idx, xs = run(m, x, torch.float32, max_layers=11)
+    check_tier2(xs, w, q, idx, levels=11)
+
+
+def test_gram_sees_weight_edits():
+    """The packed blocks are rebuilt after an in-place edit of ANY level (the reference reads weights live)."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(8, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    x = synth.activations(13, 512, cfg["dim"])
+    for arm in ("gram", "exact"):
+        m = make_model(cfg, w, arm)
+        _, before, _ = run(m, x, torch.float32)
+        with torch.no_grad():
+            m.layers[3][0].weight.mul_(-1.0)
+        _, after, _ = run(m, x, torch.float32)
+        assert np.array_equal(after[:, :3], before[:, :3]) and not np.array_equal(after[:, 3:], before[:, 3:])
+        w2 = {k: v.copy() for k, v in w.items()}
+        w2["w_in"][3] *= -1.0
+        if arm == "exact":
+            assert np.array_equal(after, oracle.forward(x, w2)[1])
+
+
+def test_gram_captures_into_a_hip_graph():
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(3, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    x = torch.from_numpy(synth.activations(2, 2048, cfg["dim"])).to(DEV).view(1, 2048, -1)
+    with torch.inference_mode():
+        q0, i0 = m(x)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x)
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            q1, i1 = m(x)
+        q1.zero_(); i1.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(i0, i1) and torch.equal(q0, q1)
+
+
+def test_arm_auto_switches_on_batch_size():
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(6, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    auto, exact, gram = (make_model(cfg, w, a) for a in ("auto", "exact", "gram"))
+    small = torch.from_numpy(synth.activations(1, 1024, cfg["dim"])).to(DEV).view(1, 1024, -1)
+    n = RQAE.GRAM_MIN_TOKENS
+    large = torch.from_numpy(synth.activations(2, n, cfg["dim"])).to(DEV).view(1, n, -1)
+    with torch.inference_mode():
+        assert torch.equal(auto(small)[0], exact(small)[0])      # bit-equal reconstruction = the exact arm ran
+        assert torch.equal(auto(large)[0], gram(large)[0])

@@ -80,9 +80,52 @@ def test_no_cpu_fallback():
         m.decode(torch.zeros(1, 3, 2, dtype=torch.long))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.quantize(torch.zeros(1, 3, 4), 0)
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 3, 256), temperature=0.5)
+
+
+def test_training_branch_runs_on_torch_ops():
+    """Training with gradients / temperature >= 1e-7 (rqae/model.py:183-185, 218-224) is served by torch ops: the
+    straight-through estimator trains lin_in and lin_out, the gumbel branch samples; eval calls never take it."""
+    torch.manual_seed(0)
+    m = RQAE(dim=32, codebook_dim=3, codebook_size=3, num_quantizers=3).train()
+    x = torch.randn(2, 5, 32)
+    q, idx = m(x, temperature=0.7)
+    assert q.shape == (2, 5, 32) and idx.shape == (2, 5, 3) and idx.dtype == torch.int64 and q.requires_grad
+    q.square().mean().backward()
+    assert m.layers[0][0].weight.grad is not None and m.layers[2][1].weight.grad.abs().sum() > 0
+    # temperature 0 while training: deterministic argmax, still differentiable (straight-through)
+    q0, idx0 = m(x)
+    q1, idx1 = m(x)
+    assert torch.equal(idx0, idx1) and q0.requires_grad
+    # the same values as a hand-written reference level loop
+    r, tot = x, 0
+    for l in range(3):
+        p = m.layers[l][0](r)
+        u = p / p.norm(dim=-1, keepdim=True)
+        k = (u @ m.codebook[l].T).argmax(-1)
+        assert torch.equal(k, idx0[..., l])
+        y = m.layers[l][1](p + (m.codebook[l][k] - p))
+        r, tot = r - y, tot + y
+    assert torch.allclose(tot, q0, atol=1e-6)
+    cv, k = m.quantize(torch.randn(4, 3, requires_grad=True), 1, temperature=0.5)
+    assert cv.shape == (4, 3) and k.shape == (4,)
+    with torch.no_grad():            # no gradients wanted and deterministic -> the HIP path (raises on CPU)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m(x)
+
+
+def test_weights_key_sees_every_parameter():
+    m = RQAE(dim=16, codebook_dim=2, codebook_size=3, num_quantizers=5).eval()
+    k0 = m._weights_key()
+    assert m._weights_key() == k0
+    with torch.no_grad():
+        m.layers[3][0].weight.add_(1.0)          # a middle level, in place
+    assert m._weights_key() != k0
+    k1 = m._weights_key()
+    m.layers[2][1].bias.data = m.layers[2][1].bias.data.clone()   # new storage
+    assert m._weights_key() != k1
+    with pytest.raises(ValueError):
+        RQAE(dim=16, codebook_dim=2, codebook_size=3, num_quantizers=1, arm="fast")
+    assert RQAE(dim=16, codebook_dim=2, codebook_size=3, num_quantizers=1, arm="gram").arm == "gram"
 
 
 def test_product_never_imports_oracle():

@@ -61,3 +61,25 @@ def test_two_rank_timing_and_aggregation():
     assert worst >= 5 * 0.02 * 0.9                  # the slower rank (20 ms steps) sets the time
     assert worst >= sec0 * 0.999
     assert sharding.aggregate_throughput(1000, 2, 5, 0.5) == 20000.0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts one process per rank (it never touches a
+    GPU), the ranks rendezvous, time exactly K steps between barriers, and rank 0 prints ONE JSON line.  --stub swaps the
+    encode for a sleep and RCCL for gloo so the orchestration runs on CPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size_seen"] == 2 and rec["steps"] == 4
+    assert rec["config"]["tokens_per_gpu_per_step"] == 524288          # BASELINE configs[2]: 4M tokens over 8 GPUs
+    assert rec["ms_per_step"] >= 4.0 * 0.9                              # the slower rank (4 ms steps) sets the time
+    assert abs(rec["value"] - 2 * 524288 * 4 / (rec["ms_per_step"] * 4e-3)) < 1e-3 * rec["value"]

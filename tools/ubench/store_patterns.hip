@@ -5,6 +5,7 @@
 //   mode 2: per instruction  4 rows x 256 B
 //   mode 3: per instruction  1 row  x 1 KiB
 //   mode 4: mode 1, but d cut into 8 slices of 1152 B owned by different workgroups (weights-stationary layout)
+//   mode 5: mode 1 with nontemporal stores      mode 6: mode 4 with nontemporal stores
 // build: hipcc -O3 --offload-arch=gfx950 store_patterns.hip -o store_patterns ; run: ./store_patterns [N]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -12,7 +13,8 @@
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int D = 2304;
 
-template <int MODE>
+#define ST(p, v) do { if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); else *reinterpret_cast<f32x4 *>(p) = v; } while (0)
+template <int MODE_, bool NT = (MODE_ >= 5), int MODE = (MODE_ == 5 ? 1 : MODE_ == 6 ? 4 : MODE_)>
 __global__ __launch_bounds__(512) void k(float *out, long long n_tokens, int ngroups_per_wave_stride)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(512) void k(float *out, long long n_tokens, int ngr
                 for (int h = 0; h < 4; ++h) { // 32 tokens = 4 x 8
                     const long long tok = pair * 32 + 8 * h + (lane & 7);
                     const int col = slice * 288 + i * 32 + 4 * (lane >> 3);
-                    *reinterpret_cast<f32x4 *>(out + tok * D + col) = v;
+                    ST(out + tok * D + col, v);
                 }
         }
         return;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(512) void k(float *out, long long n_tokens, int ngr
         } else if (MODE == 1) {
             for (int c0 = 0; c0 < D; c0 += 32)
                 for (int h = 0; h < 4; ++h)
-                    *reinterpret_cast<f32x4 *>(out + (t0 + 8 * h + (lane & 7)) * D + c0 + 4 * (lane >> 3)) = v;
+                    ST(out + (t0 + 8 * h + (lane & 7)) * D + c0 + 4 * (lane >> 3), v);
         } else if (MODE == 2) {
             for (int c0 = 0; c0 < D; c0 += 64)
                 for (int h = 0; h < 8; ++h)
@@ -61,7 +63,7 @@ int main(int argc, char **argv)
     hipMalloc(&out, (size_t)n * D * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 5; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
         for (int grid : {256, 512, 1024}) {
             float best = 1e9f;
             for (int rep = 0; rep < 5; ++rep) {
@@ -72,6 +74,8 @@ int main(int argc, char **argv)
                 case 2: hipLaunchKernelGGL(k<2>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
                 case 3: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
                 case 4: hipLaunchKernelGGL(k<4>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
+                case 5: hipLaunchKernelGGL(k<5>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
+                case 6: hipLaunchKernelGGL(k<6>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);

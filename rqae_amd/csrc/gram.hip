@@ -317,6 +317,7 @@ struct ProjParams {
     const void *x;
     const uint16_t *win_img;
     float *P;              // [NOG][tok_pad][16]
+    float *dump;           // 1 KiB of scratch (pipelined form: stores of rows / groups that do not exist)
     long long n_tokens, tok_pad;
     int d, NOG, KSA;
 };
@@ -469,6 +470,212 @@ __global__ __launch_bounds__(A_NW * 64) void gram_project_kernel(ProjParams p)
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel A, pipelined form
+// Same arithmetic as gram_project_kernel (same fragments, same accumulators, same final sums: identical bits), different
+// data movement.  The first form mixes an LDS-DMA weight stream with plain register loads of x and ends every chunk in
+// __syncthreads(): hipcc then waits vmcnt(0) at each barrier (an LDS-DMA is a pending LDS write) and the x loads issued
+// at the top of the chunk are drained with it -- every chunk pays a full HBM round trip (measured: 0.30 ms for a 1.2 GB
+// read that the same access pattern streams in 0.195 ms, profiles/r02_load_patterns.txt).  Here every vector-memory
+// operation of the main loop is an asm statement hipcc does not count, and the waits are counted by hand:
+//   * weights: 3-stage LDS ring filled by global_load_lds_dwordx4, chunk cc+2 issued while chunk cc is multiplied;
+//   * x: straight to registers (every byte is used by one wave), a 3-deep register ring, chunk cc+2 issued with it;
+//   * per chunk ONE s_waitcnt vmcnt(#x loads of a chunk) -- the newest group stays in flight -- and ONE raw s_barrier.
+// One workgroup = 8 waves x 32 tokens; KC k-steps per chunk (4 for 2-byte x, 2 for fp32 x: the ring holds 3 KC x-fragments).
+constexpr int A2_NW = 8;
+constexpr int A2_NS = 3;
+
+template <int XT> struct XRaw;
+template <> struct XRaw<RQAE_X_BF16> { static constexpr int NLD = 1, KC = 4, ESZ = 2; };
+template <> struct XRaw<RQAE_X_F16> { static constexpr int NLD = 1, KC = 4, ESZ = 2; };
+template <> struct XRaw<RQAE_X_F32> { static constexpr int NLD = 2, KC = 2, ESZ = 4; };
+
+template <int XT>
+__device__ __forceinline__ void xparts(const u32x4 (&raw)[XRaw<XT>::NLD], u32x4 (&o)[3])
+{
+    XFrag<XT> f;
+    if constexpr (XT == RQAE_X_F32) { f.raw0 = raw[0]; f.raw1 = raw[1]; } else { f.raw = raw[0]; }
+    f.parts(o);
+}
+
+__device__ __forceinline__ const void *uniform_ptr(const void *p)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned long long u = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
+                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32);
+    return reinterpret_cast<const void *>(u);
+}
+
+// one 1-KiB LDS-DMA piece: lane i moves 16 bytes from g_uniform + 16 i to LDS byte address lds_addr + 16 i (M0 saved/restored)
+__device__ __forceinline__ void dma_piece(const void *g_uniform, unsigned lds_addr, unsigned lane_byte_off)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(g_uniform), "s"(lds_addr)
+                 : "memory");
+}
+
+// ABL: compile-time ablation bits for tools/ builds (-DRQAE_GRAM_ABLATE; 0 in the product): 1 = no MFMAs, 2 = no weight
+// DMA, 4 = no barrier, 8 = no fragment reads from LDS
+template <int XT, int ABL = 0>
+__global__ __launch_bounds__(A2_NW * 64) void gram_project2_kernel(ProjParams p)
+{
+    constexpr int KC = XRaw<XT>::KC, NLD = XRaw<XT>::NLD, ESZ = XRaw<XT>::ESZ;
+    constexpr int STAGE = KC * 9 * 1024;
+    constexpr int XLOADS = KC * A_TT * NLD;          // x loads per chunk and wave
+    constexpr int PSTORES = 3 * A_TT;                // P stores per tile and wave (issued whether or not the rows exist: see below)
+    static_assert(XLOADS == 8, "the wait statements below name 8 x registers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
+    const int ug0 = blockIdx.y * 3;
+    const size_t rowb = (size_t)p.d * ESZ;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int nchunks = p.KSA / KC;
+    constexpr int TILE = A2_NW * 16 * A_TT;          // tokens per workgroup tile
+    const long long ntiles = (p.n_tokens + TILE - 1) / TILE;
+    // persistent: this workgroup owns tiles blockIdx.x, blockIdx.x + gridDim.x, ...; their chunks form ONE stream
+    // s = 0 .. S-1 (tile s / nchunks, chunk s % nchunks), so the prefetch runs across tile boundaries
+    const long long mytiles = ntiles > blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long long S = mytiles * nchunks;
+    if (S == 0) return;
+
+    f32x4 acc[3][3][A_TT];
+    u32x4 xr[A2_NS][KC][A_TT][NLD];
+
+    // lane's row offset from its tile's first row; rows past the end re-read the last row (their results are not stored)
+    auto row_off = [&](long long tile, int T) -> unsigned {
+        const long long tile0 = tile * TILE;
+        long long r = tile0 + (long long)wave * (16 * A_TT) + 16 * T + n;
+        r = r < p.n_tokens ? r : p.n_tokens - 1;
+        return (unsigned)((r - tile0) * (long long)rowb) + (unsigned)(g * 8 * ESZ);
+    };
+    // group s = this wave's weight pieces of the chunk (LDS-DMA) followed by its x fragments (registers), in that order.
+    // Streams past the end (s >= S: at most 4 groups per workgroup) repeat the last chunk: the operation counts stay static.
+    // (xr is passed in: clang rejects asm operands that name captures of a generic lambda)
+    long long iti = 0;     // issue stream position: tile ordinal (of this workgroup's tiles) and chunk
+    int icc = 0;
+    auto issue = [&](auto slot_c, u32x4 (&xr)[A2_NS][KC][A_TT][NLD]) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        const int cc = icc;
+        const long long tile = blockIdx.x + iti * gridDim.x;
+        if (!(iti == mytiles - 1 && icc == nchunks - 1)) {   // advance; at the end of the stream stay on the last chunk
+            if (++icc == nchunks) { icc = 0; ++iti; }
+        }
+        for (int q = wave; q < ((ABL & 2) ? 0 : KC * 9); q += A2_NW) {
+            const int k = q / 9, f = q - k * 9, u = f / 3;
+            const int uu = ug0 + u < p.NOG ? ug0 + u : p.NOG - 1;     // groups past the last one: any valid fragment (never stored)
+            const void *src = uniform_ptr(p.win_img + ((((size_t)(cc * KC + k) * p.NOG + uu) * 3 + (f - 3 * u)) * 512));
+            dma_piece(src, lds0 + SLOT * STAGE + (k * 9 + f) * 1024, lane16);
+        }
+        const void *xb = uniform_ptr(static_cast<const char *>(p.x) + (size_t)tile * TILE * rowb + (size_t)cc * KC * 32 * ESZ);
+        unsigned voff[A_TT];
+#pragma unroll
+        for (int T = 0; T < A_TT; ++T) voff[T] = row_off(tile, T);
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int T = 0; T < A_TT; ++T)
+#pragma unroll
+                for (int h = 0; h < NLD; ++h)
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3"
+                                 : "=v"(xr[SLOT][k][T][h])
+                                 : "v"(voff[T]), "s"(xb), "i"(k * 32 * ESZ + 16 * h)
+                                 : "memory");
+    };
+    // ONE statement holds the wait and names the eight destinations, so no use or copy of them can be placed above the wait
+    auto landed = [&](auto slot_c, u32x4 (&xr)[A2_NS][KC][A_TT][NLD]) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        u32x4 *r = &xr[SLOT][0][0][0];
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                     : "n"(XLOADS + PSTORES)
+                     : "memory");
+    };
+
+    issue(std::integral_constant<int, 0>{}, xr);
+    issue(std::integral_constant<int, 1>{}, xr);
+    bool after_tile_end = false;       // the previous chunk ended a tile: its P stores are younger than group s+1
+    long long cti = 0;                 // compute stream position
+    int ccc = 0;
+    for (long long s0 = 0; s0 < S; s0 += A2_NS) {
+        static_for<0, A2_NS>([&](auto ph_c) {
+            constexpr int PH = decltype(ph_c)::value;
+            const long long s = s0 + PH;
+            // Group s has landed when only the x loads of group s+1 are younger (vmcnt(8)) -- or, right after a tile end,
+            // those and the tile's P stores (vmcnt(8 + 6)).  The operand-free statement is the stricter, conditional one.
+            if (!after_tile_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XLOADS) : "memory");
+            landed(ph_c, xr);
+            if (!(ABL & 4)) __builtin_amdgcn_s_barrier();       // every wave's pieces of stage PH landed; every wave has left chunk s-1
+            const long long ti = cti;
+            const int cc = ccc;
+            if (s < S) {
+                if (++ccc == nchunks) { ccc = 0; ++cti; }
+                if (cc == 0) {
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                            for (int T = 0; T < A_TT; ++T) acc[u][pp][T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const char *wb = smem + PH * STAGE + lane * 16;
+                // The chunk's KC*9 weight fragments, each feeding MF MFMAs.  Written as "all reads, then all MFMAs" and
+                // put in order by sched_group_barrier: PF reads ahead, then one read per fragment's MFMAs -- left to
+                // itself hipcc reads two fragments, waits for them, multiplies, and so exposes the LDS latency 18 times
+                // per chunk (measured: 0.31 ms per 262144 tokens, no better than the unpipelined form).
+                constexpr int NF = KC * 9, MF = A_TT * XFrag<XT>::NP, PF = 6;
+                u32x4 xp[KC][A_TT][3];
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+#pragma unroll
+                    for (int T = 0; T < A_TT; ++T) xparts<XT>(xr[PH][k][T], xp[k][T]);
+                u32x4 fr[NF];
+#pragma unroll
+                for (int i = 0; i < NF; ++i) fr[i] = (ABL & 8) ? xp[i % KC][0][0] : *reinterpret_cast<const u32x4 *>(wb + i * 1024);
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    const int k = i / 9, u = (i % 9) / 3, pp = i % 3;
+#pragma unroll
+                    for (int T = 0; T < A_TT; ++T)
+#pragma unroll
+                        for (int xq = 0; xq < XFrag<XT>::NP; ++xq) {
+                            if (ABL & 1) { if (i < KC * A_TT) acc[u][pp][T] += __builtin_bit_cast(f32x4, xp[k][T][xq] ^ fr[i]); }
+                            else acc[u][pp][T] = mfma16(fr[i], xp[k][T][xq], acc[u][pp][T]);
+                        }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+                for (int i = 0; i < NF - PF; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, PF * MF, 0);
+            }
+            // stage (s+2) % 3 was read last in chunk s-1, which every wave left before the barrier above
+            issue(std::integral_constant<int, (PH + 2) % A2_NS>{}, xr);
+            after_tile_end = (s < S) && (cc == nchunks - 1);
+            if (after_tile_end) {
+                // D layout: lane (g, n) holds outputs 4g..4g+3 of token n; pieces summed small to large.  Exactly PSTORES
+                // store instructions per wave (rows past the end and groups past the last go to a dump row of the
+                // workspace), so the wait above can count them.
+                const long long tile = blockIdx.x + ti * gridDim.x;
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int T = 0; T < A_TT; ++T) {
+                        const long long tok = tile * TILE + (long long)wave * (16 * A_TT) + 16 * T + n;
+                        const bool live = tok < p.n_tokens && ug0 + u < p.NOG;
+                        const f32x4 v = (acc[u][2][T] + acc[u][1][T]) + acc[u][0][T];
+                        float *dst = live ? p.P + (((size_t)(ug0 + u) * p.tok_pad + tok) * 16 + 4 * g) : p.dump + lane * 4;
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    }
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated groups past the end of the stream
 }
 
 // ------------------------------------------------------------------------------------------------ kernel B: levels
@@ -952,6 +1159,7 @@ constexpr int B_NW = 8;
 struct Tuning {
     int c_tt;            // reconstruct kernel: 16-token tiles per wave (2: 8 waves per workgroup, 1: 16 waves)
     long long chunk;     // tokens per pass
+    int proj;            // projection kernel: 2 = pipelined form (default), 1 = first form
 };
 const Tuning &tuning()
 {
@@ -959,6 +1167,8 @@ const Tuning &tuning()
         Tuning v;
         v.chunk = 262144;
         v.c_tt = 2;
+        v.proj = 2;
+        if (const char *e = getenv("RQAE_GRAM_PROJ")) v.proj = atoi(e) == 1 ? 1 : 2;
         if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
         if (const char *e = getenv("RQAE_GRAM_CHUNK")) { const long long c = atoll(e); if (c >= 64) v.chunk = (c + 63) & ~63LL; }
         return v;
@@ -1012,7 +1222,7 @@ size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
 {
     const long long ch = n_tokens < tuning().chunk ? n_tokens : tuning().chunk;
     const long long tp = pad64(ch);
-    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + al256((size_t)nks_recon(g, levels) * tp * 64);
+    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + al256((size_t)nks_recon(g, levels) * tp * 64) + 1024;
 }
 
 bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 <= 150 * 1024; }
@@ -1114,6 +1324,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     const long long tp = pad64(chunk);
     float *P = static_cast<float *>(workspace);
     unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)g.NOG * tp * 16 * sizeof(float)));
+    float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg) + al256((size_t)nks_recon(g, levels) * tp * 64));
 
     for (long long t0 = 0; t0 < n_tokens; t0 += chunk) {
         const long long nt = n_tokens - t0 < chunk ? n_tokens - t0 : chunk;
@@ -1122,8 +1333,37 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         // ---- A
         ProjParams pa;
         pa.x = static_cast<const char *>(x) + (size_t)t0 * d * xs;
-        pa.win_img = v.win_img; pa.P = P; pa.n_tokens = nt; pa.tok_pad = tp; pa.d = d; pa.NOG = g.NOG; pa.KSA = g.KSA;
-        {
+        pa.win_img = v.win_img; pa.P = P; pa.dump = dump; pa.n_tokens = nt; pa.tok_pad = tp; pa.d = d; pa.NOG = g.NOG; pa.KSA = g.KSA;
+        if (tuning().proj == 2 && g.KSA % 4 == 0) {
+            const unsigned ny = (unsigned)((g.NOG + 2) / 3);
+            long long gx = (nt + A2_NW * 16 * A_TT - 1) / (A2_NW * 16 * A_TT);     // persistent: one workgroup per CU walks the tiles
+            const long long cap = ncu / ny > 0 ? ncu / ny : 1;
+            if (gx > cap) gx = cap;
+            const dim3 grid((unsigned)gx, ny);
+            auto go = [&](auto kern, int kc) -> int {
+                const size_t lds = (size_t)A2_NS * kc * 9 * 1024;
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, grid, dim3(A2_NW * 64), lds, s, pa);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            int rc;
+#ifdef RQAE_GRAM_ABLATE
+            static const int abl = getenv("RQAE_GRAM_ABL") ? atoi(getenv("RQAE_GRAM_ABL")) : 0;
+            if (x_dtype == RQAE_X_BF16 && abl) {
+                switch (abl) {
+#define ABLC(N) case N: rc = go(gram_project2_kernel<RQAE_X_BF16, N>, XRaw<RQAE_X_BF16>::KC); break;
+                ABLC(1) ABLC(2) ABLC(3) ABLC(4) ABLC(5) ABLC(7) ABLC(8) ABLC(9) ABLC(11) ABLC(15)
+#undef ABLC
+                default: return gfail("RQAE_GRAM_ABL=%d not instantiated", abl);
+                }
+            } else
+#endif
+            if (x_dtype == RQAE_X_BF16) rc = go(gram_project2_kernel<RQAE_X_BF16>, XRaw<RQAE_X_BF16>::KC);
+            else if (x_dtype == RQAE_X_F16) rc = go(gram_project2_kernel<RQAE_X_F16>, XRaw<RQAE_X_F16>::KC);
+            else rc = go(gram_project2_kernel<RQAE_X_F32>, XRaw<RQAE_X_F32>::KC);
+            if (rc) return rc;
+        } else {
             const dim3 grid((unsigned)((nt + A_NW * 16 * A_TT - 1) / (A_NW * 16 * A_TT)), (unsigned)((g.NOG + 2) / 3));
             const size_t lds = 2 * A_BUF;
             auto go = [&](auto kern) -> int {

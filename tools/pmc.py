@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--kernels", default="gram_|rqae_", help="regex on kernel names to keep")
     ap.add_argument("--pass", dest="passes", action="append", default=None)
+    ap.add_argument("--pass-timeout", type=int, default=150, help="seconds per rocprofv3 pass")
     ap.add_argument("--skip-launches", type=int, default=0, help="ignore the first N launches of each kernel (warm-up)")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     args = ap.parse_args()
@@ -49,11 +50,17 @@ def main():
     for pi, counters in enumerate(passes):
         d = tempfile.mkdtemp(prefix=f"pmc{pi}_", dir="/tmp")
         full = ["rocprofv3", "--pmc", *counters.split(), "--output-format", "csv", "-d", d, "-o", "p", "--", *cmd]
-        r = subprocess.run(full, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        print(f"pass {pi}: {counters}", flush=True)
+        try:
+            r = subprocess.run(full, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.pass_timeout)
+        except subprocess.TimeoutExpired:
+            print(f"pass {pi} timed out after {args.pass_timeout} s -- skipped", flush=True)
+            continue
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
-            print(r.stdout[-3000:], file=sys.stderr)
-            sys.exit(f"pass {pi} ({counters}) failed rc={r.returncode}, csv files: {files}")
+            print(r.stdout[-1500:], flush=True)
+            print(f"pass {pi} ({counters}) failed rc={r.returncode}, csv files: {files} -- skipped", flush=True)
+            continue
         per = {}   # (kernel, dispatch) -> {counter: value}
         dur = {}
         for f in files:

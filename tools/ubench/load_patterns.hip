@@ -5,6 +5,7 @@
 //   mode 2: per instruction  2 rows x 512 B to registers
 //   mode 3: mode 1 by LDS-DMA (global_load_lds_dwordx4), pieces land in a per-wave LDS ring
 //   mode 4: mode 2 by LDS-DMA
+//   mode 5: mode 0 addresses in the project kernel's schedule (groups of DEPTH loads, two groups in flight, wait for a whole group)
 // build: hipcc -O3 --offload-arch=gfx950 load_patterns.hip -o load_patterns ; run: ./load_patterns [N]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,11 +27,33 @@ __global__ __launch_bounds__(512) void k(const char *x, unsigned *sink, long lon
         // a group = 32 rows x 4608 B = 144 KiB = 144 instructions of 1 KiB
         constexpr int NI = 144;
         auto addr = [&](int i) -> const char * {
-            if (MODE == 0) { const int h = i & 1, c = i >> 1; return base + (size_t)(16 * h + (lane & 15)) * ROWB + c * 64 + 16 * (lane >> 4); }
+            if (MODE == 0 || MODE == 5) { const int h = i & 1, c = i >> 1; return base + (size_t)(16 * h + (lane & 15)) * ROWB + c * 64 + 16 * (lane >> 4); }
             if (MODE == 1 || MODE == 3) { const int h = i & 3, c = i >> 2; return base + (size_t)(8 * h + (lane >> 3)) * ROWB + c * 128 + 16 * (lane & 7); }
             { const int h = i & 15, c = i >> 4; return base + (size_t)(2 * h + (lane >> 5)) * ROWB + c * 512 + 16 * (lane & 31); }
         };
-        if (MODE <= 2) {
+        if (MODE == 5) {
+            // the project kernel's schedule: groups of DEPTH loads (mode 0 addresses), two groups in flight, wait for ALL of
+            // the older group, then issue the next one
+            u32x4 a[DEPTH], b[DEPTH];
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) a[j] = *reinterpret_cast<const u32x4 *>(addr(j));
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) b[j] = *reinterpret_cast<const u32x4 *>(addr(DEPTH + j));
+            for (int i = 2 * DEPTH; i < NI + 2 * DEPTH; i += 2 * DEPTH) {
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) acc ^= a[j];
+                asm volatile("" : "+v"(acc)::"memory");
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) a[j] = *reinterpret_cast<const u32x4 *>(addr(i + j < NI ? i + j : NI - 1));
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) acc ^= b[j];
+                asm volatile("" : "+v"(acc)::"memory");
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) b[j] = *reinterpret_cast<const u32x4 *>(addr(i + DEPTH + j < NI ? i + DEPTH + j : NI - 1));
+            }
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) acc ^= a[j] ^ b[j];
+        } else if (MODE <= 2) {
             u32x4 v[DEPTH];
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) v[j] = *reinterpret_cast<const u32x4 *>(addr(j));
@@ -82,24 +105,30 @@ void run(const char *x, unsigned *sink, long long n, hipEvent_t e0, hipEvent_t e
     }
 }
 
+__global__ void fill_random(unsigned *p, size_t nwords)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned v = (unsigned)i * 2654435761u + 12345u;
+        v ^= v << 13; v ^= v >> 17; v ^= v << 5;
+        p[i] = v;
+    }
+}
+
 int main(int argc, char **argv)
 {
     const long long n = argc > 1 ? atoll(argv[1]) : 262144;
+    const int random_data = argc > 2 ? atoi(argv[2]) : 0;      // 0: constant bytes, 1: pseudo-random words
     char *x; unsigned *sink;
     hipMalloc(&x, (size_t)n * ROWB);
     hipMalloc(&sink, 64);
-    hipMemset(x, 1, (size_t)n * ROWB);
+    if (random_data) hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, reinterpret_cast<unsigned *>(x), (size_t)n * ROWB / 4);
+    else hipMemset(x, 1, (size_t)n * ROWB);
+    printf("data: %s\n", random_data ? "pseudo-random" : "constant");
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     run<0, 8>(x, sink, n, e0, e1);
-    run<0, 16>(x, sink, n, e0, e1);
-    run<1, 8>(x, sink, n, e0, e1);
-    run<1, 16>(x, sink, n, e0, e1);
-    run<2, 8>(x, sink, n, e0, e1);
-    run<2, 16>(x, sink, n, e0, e1);
-    run<3, 4>(x, sink, n, e0, e1);
-    run<3, 8>(x, sink, n, e0, e1);
-    run<4, 4>(x, sink, n, e0, e1);
-    run<4, 8>(x, sink, n, e0, e1);
+    run<5, 8>(x, sink, n, e0, e1);
+    run<5, 4>(x, sink, n, e0, e1);
+    run<5, 16>(x, sink, n, e0, e1);
     return 0;
 }

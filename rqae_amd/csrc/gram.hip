@@ -273,8 +273,11 @@ __global__ void gram_pack_cb_kernel(Geom g, const float *codebook, uint16_t *img
         const int lv = (int)(f / g.KTP);
         const int row = 16 * tile + (lane & 15), s = 32 * ks + 8 * (lane >> 4) + j;
         const int comp = s / 6, term = s % 6;
+        // rows past K repeat row 0: a repeat can tie with, never beat, the row it repeats, and ties go to the lower row
+        // block -- so a scan over whole tiles needs no masking (gram_fused_kernel; gram_levels_kernel masks anyway)
+        const int rsrc = row < g.K ? row : 0;
         float v = 0.0f;
-        if (row < g.K && comp < g.c) v = codebook[((size_t)lv * g.K + row) * g.c + comp];
+        if (comp < g.c) v = codebook[((size_t)lv * g.K + rsrc) * g.c + comp];
         img[i] = piece_of(v, APART[term]);
     }
     const size_t nf = (size_t)lcb * g.K * g.c, nall = nf + 64 * g.c;
@@ -1153,6 +1156,8 @@ __global__ __launch_bounds__(NW * 64) void gram_reconstruct_kernel(RecParams p)
     }
 }
 
+#include "gram_fused.hpp"
+
 constexpr int B_NW = 8;
 
 // launch geometry knobs, read from the environment ONCE (first call), for measurements only
@@ -1160,6 +1165,7 @@ struct Tuning {
     int c_tt;            // reconstruct kernel: 16-token tiles per wave (2: 8 waves per workgroup, 1: 16 waves)
     long long chunk;     // tokens per pass
     int proj;            // projection kernel: 2 = pipelined form (default), 1 = first form
+    int fused;           // 1 (default): one persistent kernel where the shape allows it, 0: always the three-kernel form
 };
 const Tuning &tuning()
 {
@@ -1169,6 +1175,8 @@ const Tuning &tuning()
         v.c_tt = 2;
         v.proj = 2;
         if (const char *e = getenv("RQAE_GRAM_PROJ")) v.proj = atoi(e) == 1 ? 1 : 2;
+        v.fused = 0;   // (work in progress: correct, not yet faster than the three kernels)
+        if (const char *e = getenv("RQAE_GRAM_FUSED")) v.fused = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
         if (const char *e = getenv("RQAE_GRAM_CHUNK")) { const long long c = atoll(e); if (c >= 64) v.chunk = (c + 63) & ~63LL; }
         return v;
@@ -1222,10 +1230,16 @@ size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
 {
     const long long ch = n_tokens < tuning().chunk ? n_tokens : tuning().chunk;
     const long long tp = pad64(ch);
-    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + al256((size_t)nks_recon(g, levels) * tp * 64) + 1024;
+    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + al256((size_t)nks_recon(g, levels) * tp * 64) + 32768 + (2048 + 8 * 36 * 4) * 8;   // + dump rows + timeline stamps (tools build)
 }
 
 bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 <= 150 * 1024; }
+
+// the one-kernel form: one level group, whole chunks of 2 k-steps, everything resident fits the CU's 160 KiB of LDS
+bool fused_shape_ok(const Geom &g, int levels)
+{
+    return g.shared_cb && levels <= 8 && g.d % 64 == 0 && g.NKC == 1 && fused_lds_bytes(g.d, g.c, g.K) <= 160 * 1024;
+}
 
 int recon_nks_template(int nks)
 {
@@ -1326,6 +1340,51 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)g.NOG * tp * 16 * sizeof(float)));
     float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg) + al256((size_t)nks_recon(g, levels) * tp * 64));
 
+    if (tuning().fused && fused_shape_ok(g, levels)) {
+        FusedParams pf;
+        pf.x = x; pf.win_img = v.win_img; pf.kconst = v.kconst; pf.gneg = v.gneg; pf.cb_img = v.cb_img; pf.cb_f32 = v.cb_f32;
+        pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = q_out;
+        pf.idx = reinterpret_cast<long long *>(indices); pf.dump = dump; pf.n_tokens = n_tokens;
+        pf.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768);
+        pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c; pf.levels = levels; pf.L = L; pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET;
+        pf.NKSC = g.NKSC;
+        pf.off_cbf = (unsigned)((size_t)g.KTP * 1024);
+        pf.off_bias = pf.off_cbf + (unsigned)((((size_t)K + 64) * c * 4 + 15) & ~(size_t)15);
+        pf.off_union = pf.off_bias + (unsigned)(((size_t)d * 4 + 15) & ~(size_t)15);
+        const size_t lds = fused_lds_bytes(d, c, K);
+        long long nb = ncu & ~1;                          // an even number of workgroups (ftile_off alternates whole and half first tiles)
+        if (nb < 2) nb = 2;
+        while (nb > 2 && ftile_count(n_tokens, nb) < nb) nb -= 2;   // few tokens: no more workgroups than tiles
+        if (ftile_count(n_tokens, nb) < nb) nb = ftile_count(n_tokens, nb);
+        if (ev) for (int i = 0; i < 3; ++i) G_TRY(hipEventRecord(ev[i], s));
+        auto go = [&](auto kern) -> int {
+            G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pf);
+            G_TRY(hipGetLastError());
+            return 0;
+        };
+        const bool full = levels == 8, ceq = c == g.CP;
+        int rc;
+#ifdef RQAE_FUSED_QUICK   /* tools builds: one instantiation, for fast compile-and-look cycles */
+#define FUSED_GO(CPV, FULLV, CEQV) go(gram_fused_kernel<RQAE_X_BF16, 5, false, true>)
+#else
+#define FUSED_GO(CPV, FULLV, CEQV)                                                                                                   \
+    (x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, CPV, FULLV, CEQV>)                                                   \
+                            : x_dtype == RQAE_X_F16 ? go(gram_fused_kernel<RQAE_X_F16, CPV, FULLV, CEQV>) : go(gram_fused_kernel<RQAE_X_F32, CPV, FULLV, CEQV>))
+#endif
+        // (FULL = true, no per-level depth branches, is not instantiated: without the branches hipcc's scheduler runs the
+        //  eight levels together and spills -- 256 VGPRs + 276 bytes of scratch against 200 VGPRs)
+        (void)full;
+        if (g.CP == 4) rc = ceq ? FUSED_GO(4, false, true) : FUSED_GO(4, false, false);
+        else rc = ceq ? FUSED_GO(5, false, true) : FUSED_GO(5, false, false);
+#undef FUSED_GO
+        if (rc) return rc;
+        if (ev) G_TRY(hipEventRecord(ev[3], s));
+        return 0;
+    }
+#ifdef RQAE_FUSED_QUICK
+    return gfail("tools build: only the fused kernel is compiled in");
+#else
     for (long long t0 = 0; t0 < n_tokens; t0 += chunk) {
         const long long nt = n_tokens - t0 < chunk ? n_tokens - t0 : chunk;
         const bool mark = ev && t0 + chunk >= n_tokens;
@@ -1444,6 +1503,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         if (mark) G_TRY(hipEventRecord(ev[3], s));
     }
     return 0;
+#endif
 }
 }  // namespace
 

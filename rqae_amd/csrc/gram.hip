@@ -115,6 +115,7 @@ __host__ __device__ inline int nks_recon(const Geom &g, int levels)
 }
 
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
+__host__ __device__ constexpr size_t pad1k(size_t v) { return (v + 1023) & ~size_t(1023); }
 
 struct GLayout {
     size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, total;
@@ -129,9 +130,9 @@ GLayout make_glayout(const Geom &g)
     lo.gneg = off;        off += al256(sizeof(float) * (size_t)g.L * g.L * g.GB);
     const int lcb = g.shared_cb ? 1 : g.L;
     lo.cb_img = off;      off += al256((size_t)lcb * g.KTP * g.NKC * 1024);
-    lo.cb_f32 = off;      off += al256(sizeof(float) * ((size_t)lcb * g.K * g.c + 64 * g.c));   // + slack: quad-row reads of pad rows
+    lo.cb_f32 = off;      off += al256(pad1k(sizeof(float) * ((size_t)lcb * g.K * g.c + 64 * g.c)));   // + slack: quad-row reads of pad rows; whole KiB: staged by 1-KiB LDS-DMA pieces
     lo.wout_img = off;    off += al256((size_t)g.NET * g.NKSC * 1024);
-    lo.bias_prefix = off; off += al256(sizeof(float) * (size_t)g.L * g.d);
+    lo.bias_prefix = off; off += al256(sizeof(float) * (size_t)g.L * g.d + 1024);                        // + 1 KiB: the fused kernel stages a row in whole 1-KiB pieces
     lo.total = off;
     return lo;
 }
@@ -907,11 +908,15 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
                     };
 #pragma unroll
                     for (int i = 0; i < 4; ++i) rescore4(16 * (4 * bgr + i) + 4 * bg);
-                    if (amb) {
-                        // equal maxima in one 64-row block on several lanes (duplicate rows): rescan the block in row order
-                        brow = 64 * bgr;
-                        bsc = -INFINITY;
-                        for (int r0 = 64 * bgr; r0 < 64 * bgr + 64; r0 += 4) rescore4(r0);
+                    // equal maxima in one 64-row block on several lanes (duplicate rows): rescan the block in row order; rare, so
+                    // the wave branches around it (a per-lane `if` alone is if-converted into every level of every token)
+                    if (__builtin_amdgcn_ballot_w64(amb) != 0) {
+                        if (amb) {
+                            brow = 64 * bgr;
+                            bsc = -INFINITY;
+#pragma unroll 1
+                            for (int r0 = 64 * bgr; r0 < 64 * bgr + 64; r0 += 4) rescore4(r0);
+                        }
                     }
                     if (!okq) brow = 0;
                     codes[li] = brow;
@@ -1165,7 +1170,8 @@ struct Tuning {
     int c_tt;            // reconstruct kernel: 16-token tiles per wave (2: 8 waves per workgroup, 1: 16 waves)
     long long chunk;     // tokens per pass
     int proj;            // projection kernel: 2 = pipelined form (default), 1 = first form
-    int fused;           // 1 (default): one persistent kernel where the shape allows it, 0: always the three-kernel form
+    int fused;           // 1: one persistent kernel where the shape allows it, 0: always the three-kernel form
+    int stagger;         // fused kernel: 1 = half first tile on odd workgroups
 };
 const Tuning &tuning()
 {
@@ -1175,8 +1181,10 @@ const Tuning &tuning()
         v.c_tt = 2;
         v.proj = 2;
         if (const char *e = getenv("RQAE_GRAM_PROJ")) v.proj = atoi(e) == 1 ? 1 : 2;
-        v.fused = 0;   // (work in progress: correct, not yet faster than the three kernels)
+        v.fused = 1;
         if (const char *e = getenv("RQAE_GRAM_FUSED")) v.fused = atoi(e) != 0;
+        v.stagger = 0;
+        if (const char *e = getenv("RQAE_GRAM_STAGGER")) v.stagger = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
         if (const char *e = getenv("RQAE_GRAM_CHUNK")) { const long long c = atoll(e); if (c >= 64) v.chunk = (c + 63) & ~63LL; }
         return v;
@@ -1340,22 +1348,19 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)g.NOG * tp * 16 * sizeof(float)));
     float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg) + al256((size_t)nks_recon(g, levels) * tp * 64));
 
-    if (tuning().fused && fused_shape_ok(g, levels)) {
+    if (tuning().fused && x_dtype != RQAE_X_F32 && fused_shape_ok(g, levels)) {
         FusedParams pf;
         pf.x = x; pf.win_img = v.win_img; pf.kconst = v.kconst; pf.gneg = v.gneg; pf.cb_img = v.cb_img; pf.cb_f32 = v.cb_f32;
         pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = q_out;
         pf.idx = reinterpret_cast<long long *>(indices); pf.dump = dump; pf.n_tokens = n_tokens;
         pf.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768);
         pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c; pf.levels = levels; pf.L = L; pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET;
-        pf.NKSC = g.NKSC;
-        pf.off_cbf = (unsigned)((size_t)g.KTP * 1024);
-        pf.off_bias = pf.off_cbf + (unsigned)((((size_t)K + 64) * c * 4 + 15) & ~(size_t)15);
-        pf.off_union = pf.off_bias + (unsigned)(((size_t)d * 4 + 15) & ~(size_t)15);
+        pf.NKSC = g.NKSC; pf.stagger = tuning().stagger;
         const size_t lds = fused_lds_bytes(d, c, K);
         long long nb = ncu & ~1;                          // an even number of workgroups (ftile_off alternates whole and half first tiles)
         if (nb < 2) nb = 2;
-        while (nb > 2 && ftile_count(n_tokens, nb) < nb) nb -= 2;   // few tokens: no more workgroups than tiles
-        if (ftile_count(n_tokens, nb) < nb) nb = ftile_count(n_tokens, nb);
+        while (nb > 2 && ftile_count(n_tokens, nb, pf.stagger) < nb) nb -= 2;   // few tokens: no more workgroups than tiles
+        if (ftile_count(n_tokens, nb, pf.stagger) < nb) nb = ftile_count(n_tokens, nb, pf.stagger);
         if (ev) for (int i = 0; i < 3; ++i) G_TRY(hipEventRecord(ev[i], s));
         auto go = [&](auto kern) -> int {
             G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1363,20 +1368,15 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             G_TRY(hipGetLastError());
             return 0;
         };
-        const bool full = levels == 8, ceq = c == g.CP;
+        const bool ceq = c == g.CP;
         int rc;
 #ifdef RQAE_FUSED_QUICK   /* tools builds: one instantiation, for fast compile-and-look cycles */
-#define FUSED_GO(CPV, FULLV, CEQV) go(gram_fused_kernel<RQAE_X_BF16, 5, false, true>)
+#define FUSED_GO(CPV, CEQV) go(gram_fused_kernel<RQAE_X_BF16, 5, true>)
 #else
-#define FUSED_GO(CPV, FULLV, CEQV)                                                                                                   \
-    (x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, CPV, FULLV, CEQV>)                                                   \
-                            : x_dtype == RQAE_X_F16 ? go(gram_fused_kernel<RQAE_X_F16, CPV, FULLV, CEQV>) : go(gram_fused_kernel<RQAE_X_F32, CPV, FULLV, CEQV>))
+#define FUSED_GO(CPV, CEQV) (x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, CPV, CEQV>) : go(gram_fused_kernel<RQAE_X_F16, CPV, CEQV>))
 #endif
-        // (FULL = true, no per-level depth branches, is not instantiated: without the branches hipcc's scheduler runs the
-        //  eight levels together and spills -- 256 VGPRs + 276 bytes of scratch against 200 VGPRs)
-        (void)full;
-        if (g.CP == 4) rc = ceq ? FUSED_GO(4, false, true) : FUSED_GO(4, false, false);
-        else rc = ceq ? FUSED_GO(5, false, true) : FUSED_GO(5, false, false);
+        if (g.CP == 4) rc = ceq ? FUSED_GO(4, true) : FUSED_GO(4, false);
+        else rc = ceq ? FUSED_GO(5, true) : FUSED_GO(5, false);
 #undef FUSED_GO
         if (rc) return rc;
         if (ev) G_TRY(hipEventRecord(ev[3], s));

@@ -1,21 +1,27 @@
 // gram_fused.hpp -- the matrix-core arm as ONE persistent kernel (included by gram.hip inside its anonymous namespace).
 //
 // The three-kernel form (project, levels, reconstruct) moves 0.37 GB of intermediates through HBM per 262144 tokens and
-// runs a read-bound, a compute-bound and a write-bound phase one after the other on the whole chip; HBM is what limits
-// the two memory phases (profiles/r02_rw_overlap.txt: one CU alone reads 58 GB/s and writes 128 GB/s, 256 CUs together
-// 24 GB/s each), so a compute phase that runs while OTHER workgroups stream costs nothing.  Here a workgroup takes a tile
-// of 256 tokens through all three phases -- projections and straight-through values never leave the CU -- and the
-// workgroups of the chip drift apart, so reads, matrix-core work and writes overlap across CUs.
+// runs a read-bound, a compute-bound and a write-bound phase one after the other on the whole chip.  Here a workgroup takes
+// a tile of 256 tokens through all three phases; projections and straight-through values never leave the CU.
 //
-//   phase A  P = x W_in'   : x streamed HBM -> registers (asm loads, 3-deep ring), W_in image L2 -> LDS ring by LDS-DMA,
-//                            counted vmcnt + one raw barrier per chunk (as gram_project2_kernel)
-//   phase B  level chain   : one token per lane in c-space, cosine contraction on MFMA against the LDS-resident codebook
-//                            image, exact fp32 rescoring of the 16 best-candidate rows (as gram_levels_kernel)
-//   phase C  out = W_out cv: cv pieces in registers (B operand), W_out image L2 -> LDS ring by LDS-DMA, 128-byte store rows
+//   phase A  P = x W_in'   : x AND the W_in image arrive by LDS-DMA (x in pieces of 8 rows x 128 bytes, XOR-swizzled through
+//                            the per-lane SOURCE address so that the MFMA operand reads are conflict-free; reading x in the
+//                            MFMA operand shape, 16 rows x 64 bytes per instruction, costs the CU's address path twice as
+//                            much -- profiles/r02_fused_timeline_regloads.txt), counted vmcnt + one raw barrier per chunk
+//   phase B  level chain   : one token per lane in c-space, cosine contraction on MFMA against the codebook image, exact fp32
+//                            rescoring of the 16 best-candidate rows (as gram_levels_kernel)
+//   phase C  out = W_out cv: cv pieces in registers (B operand), W_out image by LDS-DMA through a 3-stage ring, accumulator
+//                            tiles transposed through LDS so that every store instruction writes 2 rows x 512 contiguous
+//                            bytes (a CU stores 132 GB/s in that shape and 34 GB/s in rows of 128 or 256 bytes:
+//                            profiles/r02_store_patterns_per_cu.txt)
 //
-// One workgroup = 8 waves x 32 tokens.  LDS: codebook image + fp32 codebook + bias sums stay resident; one region is the
-// W_in ring in phase A, the per-wave exchange buffers in phase B and the W_out ring in phase C.
-// Serves one level group (levels <= 8) and a shared codebook; other shapes take the three-kernel form.
+// One workgroup = 8 waves x 32 tokens, one workgroup per CU.  The three phases need different tables, so LDS is re-mapped
+// at every phase boundary (one barrier each) and the codebook image is staged again for every tile (86 KB from L2 per 256
+// tokens -- 2 % of the tile's traffic):
+//   A: [W_in ring 3 x 18 KB][x rings 8 waves x 3 x 4 KB]                          = 150 KB
+//   B: [codebook image 64 KB][fp32 codebook 22 KB][exchange 8 x 5 KB][Gram 7 KB]  = 133 KB
+//   C: [bias sums 9 KB][W_out ring 3 x 32 KB][transposition 8 x 4.1 KB]           = 138 KB      (sizes at C2)
+// Serves 2-byte x (bf16 / fp16), one level group (levels <= 8) and a shared codebook; other shapes take the three kernels.
 
 struct FusedParams {
     const void *x;
@@ -23,22 +29,27 @@ struct FusedParams {
     const float *kconst;       // [NOG * 16]
     const float *gneg;         // [L][L][GB]
     const uint16_t *cb_img;    // [KTP][512]
-    const float *cb_f32;       // [K + 64][c]
+    const float *cb_f32;       // [K + 64][c], zero padded to whole KiB
     const uint16_t *wout_img;  // [NET][NKSC][512]
-    const float *bias;         // [d]: bias_prefix[levels - 1]
+    const float *bias;         // [d] (+ slack to a whole KiB): bias_prefix[levels - 1]
     float *out;                // [n_tokens][d], or NULL: codes only
     long long *idx;            // [n_tokens][levels]
     float *dump;               // 32 KiB: stores of rows / elements that do not exist
-    unsigned long long *stamps; // tools build (-DRQAE_FUSED_TIMELINE) only: s_memtime at the phase boundaries, [wg < 8][wave][tile < 4][8]
+    unsigned long long *stamps; // tools build (-DRQAE_FUSED_TIMELINE) only: s_memtime at the phase boundaries
     long long n_tokens;
     int d, K, KTP, c, levels, L, KSA, NOG, NET, NKSC;
-    unsigned off_cbf, off_bias, off_union;   // LDS byte offsets (the codebook image is at 0)
+    int stagger;               // 1: the first tile of every odd workgroup is a half tile (ftile_off)
 };
 
 constexpr int F_NW = 8;                 // waves per workgroup
 constexpr int F_TILE = F_NW * 32;       // tokens per tile
-constexpr int F_XCHW = 5120;            // exchange bytes per wave
-constexpr int F_ETS = 4;                // element tiles per W_out stage
+constexpr int F_XCHW = 5120;            // phase B: exchange bytes per wave
+constexpr int F_ETS = 4;                // phase C: element tiles per W_out stage
+constexpr int F_XSLOT = 4096;           // phase A: one chunk of a wave's x (32 rows x 128 bytes)
+constexpr int F_TRS = 528;              // phase C: row stride of the transposition buffer (512 + 16: conflict-free writes)
+constexpr int F_TRW = 8 * F_TRS;        // phase C: transposition bytes per wave (8 token rows)
+
+
 
 template <int CP> struct FusedGeom {
     static constexpr int GL = 8;
@@ -47,37 +58,38 @@ template <int CP> struct FusedGeom {
     static constexpr int GS = ((6 * CP * GL + 31) / 32) * 32;
     static constexpr int NKS = GS / 32;                      // k-steps of the reconstruction
     static constexpr int GB = (CP * CP + 3) & ~3;
-    static constexpr int KC = 2;                             // k-steps per phase-A chunk
+    static constexpr int KC = 2;                             // k-steps per phase-A chunk: 64 elements = 128 bytes of a 2-byte row
     static constexpr int STAGE_A = KC * NG * 3 * 1024;
     static constexpr int STAGE_C = F_ETS * NKS * 1024;
-    static constexpr int XCH_ALL = F_NW * F_XCHW + GL * GL * GB * 4;     // exchange buffers + Gram blocks (phase B)
-    static constexpr int RINGS = 3 * STAGE_A > 2 * STAGE_C ? 3 * STAGE_A : 2 * STAGE_C;
-    static constexpr int UNION = RINGS > XCH_ALL ? RINGS : XCH_ALL;
+    static constexpr size_t LDS_A = 3 * (size_t)STAGE_A + F_NW * 3 * (size_t)F_XSLOT;
 };
 
 __host__ __device__ inline size_t fused_lds_bytes(int d, int c, int K)
 {
     const int CP = cp_of(c);
-    const int KTP = (((K + 15) / 16 + 3) / 4) * 4;
-    const size_t img = (size_t)KTP * 1024, cbf = (((size_t)K + 64) * c * 4 + 15) & ~(size_t)15, bias = ((size_t)d * 4 + 15) & ~(size_t)15;
-    const size_t un = CP == 4 ? FusedGeom<4>::UNION : FusedGeom<5>::UNION;
-    return img + cbf + bias + un;
+    const size_t KTP = (((size_t)(K + 15) / 16 + 3) / 4) * 4;
+    const size_t gb = (CP * CP + 3) & ~3, nks = CP == 4 ? FusedGeom<4>::NKS : FusedGeom<5>::NKS;
+    const size_t a = CP == 4 ? FusedGeom<4>::LDS_A : FusedGeom<5>::LDS_A;
+    const size_t b = KTP * 1024 + pad1k(((size_t)K + 64) * c * 4) + F_NW * F_XCHW + 64 * gb * 4;
+    const size_t cc = pad1k((size_t)d * 4) + 3 * F_ETS * nks * 1024 + F_NW * F_TRW;
+    return a > b ? (a > cc ? a : cc) : (b > cc ? b : cc);
 }
 
-// Tile schedule.  Workgroup b of G takes tiles b, b + G, b + 2G, ...  The first tile of every odd workgroup is a HALF tile:
-// all workgroups start together, and with equal tiles they would stay in step -- every CU reading, then every CU on the
-// matrix cores, then every CU writing, HBM idle a third of the time.  A half tile puts the odd workgroups half a period
-// ahead for the rest of the launch, so the phases of neighbouring CUs overlap.  ftile_off(j) = first token of tile j.
-__host__ __device__ inline long long ftile_off(long long j, long long G)
+// Tile schedule.  Workgroup b of G takes tiles b, b + G, b + 2G, ...  With stagger the first tile of every odd workgroup is a
+// HALF tile: all workgroups start together and would otherwise stay in step (every CU reading, then every CU on the matrix
+// cores, then every CU writing); a half tile puts the odd workgroups half a period ahead.  ftile_off(j) = first token of tile j.
+__host__ __device__ inline long long ftile_off(long long j, long long G, int stagger)
 {
+    if (!stagger) return 256 * j;
     return j < G ? 192 * j + ((j & 1) ? 64 : 0) : 192 * G + 256 * (j - G);
 }
-__host__ inline long long ftile_count(long long n_tokens, long long G)
+__host__ inline long long ftile_count(long long n_tokens, long long G, int stagger)
 {
+    if (!stagger) return (n_tokens + 255) / 256;
     if (n_tokens <= 192 * G) {
-        long long j = n_tokens / 192;                       // off(j) <= 192 j + 64
-        while (j > 0 && ftile_off(j, G) >= n_tokens) --j;
-        while (ftile_off(j, G) < n_tokens) ++j;
+        long long j = n_tokens / 192;
+        while (j > 0 && ftile_off(j, G, 1) >= n_tokens) --j;
+        while (ftile_off(j, G, 1) < n_tokens) ++j;
         return j;
     }
     return G + (n_tokens - 192 * G + 255) / 256;
@@ -107,48 +119,56 @@ __device__ __forceinline__ void wave_sync_lds()
 #define F_STAMPA(s_, i) do { } while (0)
 #endif
 
-// FULL: levels == 8 (no per-level depth checks); CEQ: c == CP (codebook rows are CP floats apart: aligned float4 row quads)
-template <int XT, int CP, bool FULL, bool CEQ>
+// CEQ: c == CP (codebook rows are CP floats apart: aligned float4 row quads)
+template <int XT, int CP, bool CEQ>
 __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 {
     using G = FusedGeom<CP>;
     constexpr int GL = G::GL, NG = G::NG, NKS = G::NKS, GB = G::GB, KC = G::KC, STAGE_A = G::STAGE_A, STAGE_C = G::STAGE_C;
-    constexpr int NLD = XRaw<XT>::NLD, ESZ = XRaw<XT>::ESZ;
+    static_assert(XRaw<XT>::ESZ == 2, "x rows are staged as 128-byte pieces of 64 two-byte elements");
     constexpr int FPK = NG * 3;                    // W_in fragments per k-step
-    constexpr int XLOADS = KC * A_TT * NLD;        // x loads per chunk and wave: 4 (2-byte x) or 8 (fp32 x)
+    constexpr int XP = 4;                          // x pieces per chunk and wave (32 rows x 128 bytes)
     static_assert(A_TT == 2, "32 tokens per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
     const int tl = lane & 31;                      // c-space: lane l works on token (l & 31) of the wave (upper half mirrors)
     const int c = CEQ ? CP : p.c;
-    const int levels = FULL ? GL : p.levels;
-    char *cbl = smem;
-    const float *cbf = reinterpret_cast<const float *>(smem + p.off_cbf);
-    const float *sbias = reinterpret_cast<const float *>(smem + p.off_bias);
-    char *un = smem + p.off_union;
-    char *xch = un + wave * F_XCHW;
-    float *sgram = reinterpret_cast<float *>(un + F_NW * F_XCHW);     // phase B only: the level group's Gram blocks [li][li2][GB]
+    const int levels = p.levels;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned lane16 = (unsigned)lane * 16u;
-    const size_t rowb = (size_t)p.d * ESZ;
-
-    // ---- resident tables: codebook image (LDS-DMA), fp32 codebook rows, bias sums
-    for (int q = wave; q < p.KTP; q += F_NW) dma_piece(uniform_ptr(p.cb_img + (size_t)q * 512), lds0 + q * 1024, lane16);
-    for (int i = tid; i < (p.K + 64) * c; i += F_NW * 64) const_cast<float *>(cbf)[i] = p.cb_f32[i];
-    for (int i = tid; i < p.d; i += F_NW * 64) const_cast<float *>(sbias)[i] = p.bias[i];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    const size_t rowb = (size_t)p.d * 2;
+    // ---- LDS maps
+    // A
+    char *wring = smem;
+    const unsigned off_xw = 3u * STAGE_A + (unsigned)wave * 3u * F_XSLOT;
+    char *xw = smem + off_xw;
+    // B
+    char *cbl = smem;
+    const unsigned off_cbf = (unsigned)p.KTP * 1024u;
+    const unsigned cbf_bytes = (unsigned)pad1k(((size_t)p.K + 64) * c * 4);
+    const float *cbf = reinterpret_cast<const float *>(smem + off_cbf);
+    char *xch = smem + off_cbf + cbf_bytes + wave * F_XCHW;
+    float *sgram = reinterpret_cast<float *>(smem + off_cbf + cbf_bytes + F_NW * F_XCHW);
+    // C
+    const float *sbias = reinterpret_cast<const float *>(smem);
+    const unsigned bias_bytes = (unsigned)pad1k((size_t)p.d * 4);
+    const unsigned off_wo = bias_bytes;
+    char *trb = smem + off_wo + 3 * STAGE_C + wave * F_TRW;
 
     const int nchunks = p.KSA / KC;
     const int wq = (tl >> 2) & 3;
+    const long long Gn = gridDim.x;
 
     int tord = 0;
-    for (long long tile = blockIdx.x; ftile_off(tile, gridDim.x) < p.n_tokens; tile += gridDim.x, ++tord) {
-        const long long tile0 = ftile_off(tile, gridDim.x);
-        long long tile_end = ftile_off(tile + 1, gridDim.x);          // rows past it belong to another tile: never stored
+    for (long long tile = blockIdx.x; ftile_off(tile, Gn, p.stagger) < p.n_tokens; tile += Gn, ++tord) {
+        const long long tile0 = ftile_off(tile, Gn, p.stagger);
+        long long tile_end = ftile_off(tile + 1, Gn, p.stagger);      // rows past it belong to another tile: never stored
         tile_end = tile_end < p.n_tokens ? tile_end : p.n_tokens;
         F_STAMP(0);
         const long long tw0 = tile0 + (long long)wave * 32;           // first token of this wave
+        // a wave without tokens (half tiles, the ragged last tile) keeps issuing its LDS-DMA pieces and meeting the barriers,
+        // and skips the arithmetic
+        const bool active = tw0 < tile_end;
         // =========================================================================================== phase A
         f32x4 acc[NG][A_TT];
 #pragma unroll
@@ -156,123 +176,113 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 #pragma unroll
             for (int T = 0; T < A_TT; ++T) acc[u][T] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
-            // per iteration s the wave issues G(s) = { x fragments of chunk s+3 (registers), its W_in pieces of chunk s+2 (LDS-DMA) }
-            // in that order, then multiplies chunk s.  Chunk s needs x(s) from G(s-3) and W(s) from G(s-2): everything older
-            // than G(s-1) must have landed, G(s-1) itself (XLOADS loads + this wave's pieces) may stay in flight.
-            constexpr int NPB = (KC * FPK) / F_NW, NPX = (KC * FPK) % F_NW;    // pieces per wave: NPB, one more on waves < NPX
-            u32x4 xr[4][KC][A_TT][NLD];
-            unsigned voff[A_TT];
+            // Piece pc of a chunk = rows 8 pc .. 8 pc + 7 of the wave x 128 bytes; lane i = (row r = i >> 3, slot jj = i & 7)
+            // lands at piece + 16 i and fetches the row's 16-byte chunk jj ^ r: LDS row r holds chunk j at slot j ^ r, and the
+            // operand reads below (lane (g, n): row n, chunk 4k + g) touch 16 different bank groups per 16-lane read group.
+            unsigned voff[XP];
 #pragma unroll
-            for (int T = 0; T < A_TT; ++T) {
-                long long r = tw0 + 16 * T + n;
-                r = r < tile_end ? r : tile_end - 1;          // rows past the tile re-read its last row
-                voff[T] = (unsigned)((r - tile0) * (long long)rowb) + (unsigned)(g * 8 * ESZ);
+            for (int pc = 0; pc < XP; ++pc) {
+                long long r = tw0 + 8 * pc + (lane >> 3);
+                r = r < tile_end ? r : tile_end - 1;          // rows past the tile re-read its last row (never stored)
+                voff[pc] = (unsigned)((r - tile0) * (long long)rowb) + (unsigned)((((lane & 7) ^ (lane >> 3)) & 7) * 16);
             }
             const char *xtile = static_cast<const char *>(p.x) + (size_t)tile0 * rowb;
-            // chunks past the end repeat the last one so that the operation counts stay static
-            auto issue_x = [&](int cc_in, auto slot_c, u32x4 (&xr)[4][KC][A_TT][NLD], const unsigned (&voff)[A_TT]) {
-                constexpr int SLOT = decltype(slot_c)::value;
-#ifdef FQ_NOX   /* tools build: every x load re-reads chunk 0 of the tile (same operation count, cache-hot lines) */
-                const int cc = 0 * cc_in;
+            // per iteration s the wave issues G(s) = { its x pieces of chunk s+2, its W_in pieces of chunk s+2 }, then multiplies
+            // chunk s: everything older than G(s-1) must have landed (x(s), W(s) are in G(s-2)), G(s-1) may stay in flight.
+            // Chunks past the end repeat the last one so that the operation counts stay static.
+            constexpr int NPB = (KC * FPK) / F_NW, NPX = (KC * FPK) % F_NW;    // W pieces per wave: NPB, one more on waves < NPX
+            auto issue = [&](int cc_in, int slot) {
+                const int cc = cc_in < nchunks ? cc_in : nchunks - 1;
+#ifdef FQ_NOX   /* tools build: every x piece re-reads chunk 0 of the tile (same operation count, cache-hot lines) */
+                const void *xb = uniform_ptr(xtile);
 #else
-                const int cc = cc_in < nchunks ? cc_in : nchunks - 1;
+                const void *xb = uniform_ptr(xtile + (size_t)cc * 128);
 #endif
-                const void *xb = uniform_ptr(xtile + (size_t)cc * KC * 32 * ESZ);
 #pragma unroll
-                for (int k = 0; k < KC; ++k)
-#pragma unroll
-                    for (int T = 0; T < A_TT; ++T)
-#pragma unroll
-                        for (int h = 0; h < NLD; ++h)
-                            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3"
-                                         : "=v"(xr[SLOT][k][T][h])
-                                         : "v"(voff[T]), "s"(xb), "i"(k * 32 * ESZ + 16 * h)
-                                         : "memory");
-            };
-            auto issue_w = [&](int cc_in, int stage) {
-                const int cc = cc_in < nchunks ? cc_in : nchunks - 1;
-#ifdef FQ_NOW   /* tools build: every W piece re-reads piece 0 (same operation count, L2-hot line) */
-                for (int q = wave; q < KC * FPK; q += F_NW) dma_piece(uniform_ptr(p.win_img), lds0 + p.off_union + stage * STAGE_A + q * 1024, lane16);
-                return;
-#endif
+                for (int pc = 0; pc < XP; ++pc) dma_piece(xb, lds0 + off_xw + slot * F_XSLOT + pc * 1024, voff[pc]);
                 for (int q = wave; q < KC * FPK; q += F_NW) {
                     const int k = q / FPK, f = q - k * FPK;
+#ifdef FQ_NOW   /* tools build: every W piece re-reads the image's first KiB */
+                    const int ks = 0 * (cc * KC + k);
+#else
                     const int ks = cc * KC + k;          // < KSA: the host sends only d % (32 KC) == 0 here
-                    dma_piece(uniform_ptr(p.win_img + (((size_t)ks * p.NOG) * 3 + f) * 512), lds0 + p.off_union + stage * STAGE_A + (k * FPK + f) * 1024, lane16);
+#endif
+                    dma_piece(uniform_ptr(p.win_img + (((size_t)ks * p.NOG) * 3 + f) * 512), lds0 + slot * STAGE_A + (k * FPK + f) * 1024, lane16);
                 }
             };
-            issue_x(0, std::integral_constant<int, 0>{}, xr, voff);                       // G(-3)
-            issue_x(1, std::integral_constant<int, 1>{}, xr, voff); issue_w(0, 0);        // G(-2)
-            issue_x(2, std::integral_constant<int, 2>{}, xr, voff); issue_w(1, 1);        // G(-1)
-            int wst = 0;                                                                  // W stage of chunk s = s % 3
-            for (int s0 = 0; s0 < nchunks; s0 += 4) {
-                static_for<0, 4>([&](auto ph_c) {
-                    constexpr int PH = decltype(ph_c)::value;
-                    const int s = s0 + PH;
-                    // operand-free, per-wave count first; then ONE statement that names the registers of slot PH, so that no use
-                    // or copy of them can be placed above the waits
-                    F_STAMPA(s, 0);
-                    if (wave < NPX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XLOADS + NPB + 1) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XLOADS + NPB) : "memory");
-                    {
-                        u32x4 *r = &xr[PH][0][0][0];
-                        if constexpr (XLOADS == 4)
-                            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(XLOADS + NPB + 1) : "memory");
-                        else
-                            asm volatile("s_waitcnt vmcnt(%8)"
-                                         : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-                                         : "n"(XLOADS + NPB + 1)
-                                         : "memory");
+            issue(0, 0);
+            issue(1, 1);
+            int st = 0;                                   // ring slot of chunk s = s % 3
+            // operand read offsets inside an x slot: lane (g, n), token tile T, k-step k
+            unsigned xro[A_TT][KC];
+#pragma unroll
+            for (int T = 0; T < A_TT; ++T)
+#pragma unroll
+                for (int k = 0; k < KC; ++k) xro[T][k] = (unsigned)((2 * T + (n >> 3)) * 1024 + (n & 7) * 128 + (((4 * k + g) ^ (n & 7)) & 7) * 16);
+            for (int s = 0; s < nchunks; ++s) {
+                F_STAMPA(s, 0);
+                if (wave < NPX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XP + NPB + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XP + NPB) : "memory");
+                __builtin_amdgcn_s_barrier();        // every wave's pieces of W(s) landed; every wave has left chunk s-1
+                F_STAMPA(s, 2);
+                issue(s + 2, st == 0 ? 2 : st - 1);  // slot (s+2) % 3 was read last in chunk s-1
+                F_STAMPA(s, 3);
+                if (active) {
+                    const char *wb = wring + st * STAGE_A + lane * 16;
+                    const char *xs = xw + st * F_XSLOT;
+                    constexpr int NF = KC * FPK, MF = A_TT * XFrag<XT>::NP, PF = 6;
+                    u32x4 xraw[KC][A_TT][1];
+#pragma unroll
+                    for (int k = 0; k < KC; ++k)
+#pragma unroll
+                        for (int T = 0; T < A_TT; ++T) xraw[k][T][0] = *reinterpret_cast<const u32x4 *>(xs + xro[T][k]);
+                    u32x4 fr[NF];
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) fr[i] = *reinterpret_cast<const u32x4 *>(wb + i * 1024);
+                    u32x4 xp[KC][A_TT][3];
+#pragma unroll
+                    for (int k = 0; k < KC; ++k)
+#pragma unroll
+                        for (int T = 0; T < A_TT; ++T) xparts<XT>(xraw[k][T], xp[k][T]);
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) {
+                        const int k = i / FPK, u = (i % FPK) / 3;
+#pragma unroll
+                        for (int T = 0; T < A_TT; ++T)
+#pragma unroll
+                            for (int xq = 0; xq < XFrag<XT>::NP; ++xq) acc[u][T] = mfma16(fr[i], xp[k][T][xq], acc[u][T]);
                     }
-                    __builtin_amdgcn_s_barrier();        // every wave's pieces of W(s) landed; every wave has left chunk s-1
-                    F_STAMPA(s, 2);
-                    // x(s+3) -> slot (s+3) % 4 (read last in chunk s-1 by this wave); W(s+2) -> stage (s+2) % 3 (read last in chunk s-1)
-                    issue_x(s + 3, std::integral_constant<int, (PH + 3) % 4>{}, xr, voff);
-                    F_STAMPA(s, 1);      // (re-used slot: after the x loads)
-                    issue_w(s + 2, wst == 0 ? 2 : wst - 1);
-                    F_STAMPA(s, 3);
-                    if (s < nchunks) {
-                        const char *wb = un + wst * STAGE_A + lane * 16;
-                        constexpr int NF = KC * FPK, MF = A_TT * XFrag<XT>::NP, PF = 6;
-                        u32x4 xp[KC][A_TT][3];
+                    // "all reads, then all MFMAs" put in order: the x operands and PF fragments ahead, then one fragment read per
+                    // fragment's MFMAs (left to itself hipcc reads two fragments, waits, multiplies: the LDS latency 18 times per chunk)
+                    __builtin_amdgcn_sched_group_barrier(0x100, KC * A_TT + PF, 0);
 #pragma unroll
-                        for (int k = 0; k < KC; ++k)
-#pragma unroll
-                            for (int T = 0; T < A_TT; ++T) xparts<XT>(xr[PH][k][T], xp[k][T]);
-                        u32x4 fr[NF];
-#pragma unroll
-                        for (int i = 0; i < NF; ++i) fr[i] = *reinterpret_cast<const u32x4 *>(wb + i * 1024);
-#pragma unroll
-                        for (int i = 0; i < NF; ++i) {
-                            const int k = i / FPK, u = (i % FPK) / 3;
-#pragma unroll
-                            for (int T = 0; T < A_TT; ++T)
-#pragma unroll
-                                for (int xq = 0; xq < XFrag<XT>::NP; ++xq) acc[u][T] = mfma16(fr[i], xp[k][T][xq], acc[u][T]);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
-#pragma unroll
-                        for (int i = 0; i < NF - PF; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x008, PF * MF, 0);
+                    for (int i = 0; i < NF - PF; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
-                    wst = wst == 2 ? 0 : wst + 1;
-                });
+                    __builtin_amdgcn_sched_group_barrier(0x008, PF * MF, 0);
+                }
+                st = st == 2 ? 0 : st + 1;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated groups past the last chunk
         }
         F_STAMP(1);
-        __builtin_amdgcn_s_barrier();    // the union region turns from the W_in ring into the exchange buffers
+        __builtin_amdgcn_s_barrier();    // LDS turns from map A into map B
         F_STAMP(2);
-        // the Gram blocks of the level group (rewritten every tile: the rings of phases A and C run over them)
-        for (int i = tid; i < GL * GL * GB; i += F_NW * 64) {
-            const int blk = i / GB, li = blk / GL, li2 = blk - li * GL;
-            sgram[i] = (li < p.L && li2 < p.L) ? p.gneg[((size_t)li * p.L + li2) * GB + (i - blk * GB)] : 0.0f;
+        // ---- map B tables: codebook image + fp32 codebook by LDS-DMA, Gram blocks of the level group by the threads
+        {
+            const int npi = p.KTP + (int)(cbf_bytes >> 10);
+            for (int q = wave; q < npi; q += F_NW) {
+                const void *src = q < p.KTP ? static_cast<const void *>(p.cb_img + (size_t)q * 512)
+                                            : static_cast<const void *>(reinterpret_cast<const char *>(p.cb_f32) + (size_t)(q - p.KTP) * 1024);
+                dma_piece(uniform_ptr(src), lds0 + q * 1024, lane16);      // the fp32 codebook follows the image
+            }
+            for (int i = tid; i < GL * GL * GB; i += F_NW * 64) {
+                const int blk = i / GB, li = blk / GL, li2 = blk - li * GL;
+                sgram[i] = (li < p.L && li2 < p.L) ? p.gneg[((size_t)li * p.L + li2) * GB + (i - blk * GB)] : 0.0f;
+            }
         }
-
-        // ---- D layout (lane (g, n): outputs 4g..4g+3 of token 16T+n) -> one token per lane, through LDS
+        // ---- D layout (lane (g, n): outputs 4g..4g+3 of token 16T+n) -> one token per lane, through the exchange buffer
         float Q[GL][CP];
         {
             float buf[NG * 16];
@@ -297,15 +307,19 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) Q[li][j] = buf[li * CP + j];
         }
-
-        __syncthreads();      // Gram blocks staged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();      // map B tables staged
         F_STAMP(3);
         // =========================================================================================== phase B
         float cvh[GL][CP];
         int codes[GL];
         static_for<0, GL>([&](auto li_c) {
             constexpr int li = decltype(li_c)::value;
-            if (FULL || li < levels) {
+#ifdef FQ_NOB   /* tools build: no level chain (codes and cv are garbage) */
+            if (li < levels && p.n_tokens < 0) {
+#else
+            if (li < levels && active) {
+#endif
                 float q[CP];
 #pragma unroll
                 for (int j = 0; j < CP; ++j) q[j] = Q[li][j];
@@ -313,6 +327,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
                 const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
+                if (li == 1) F_STAMPA(30, 0);
                 // ---- B operand rows of the wave's 32 tokens: 32 slots = 64 bytes per token
                 {
                     unsigned dw[16];
@@ -339,6 +354,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                     const int pos = (g + 2 * ((n >> 2) & 3)) & 3;
                     B[T] = *reinterpret_cast<const u32x4 *>(xch + (16 * T + n) * 64 + pos * 16);
                 }
+                if (li == 1) F_STAMPA(30, 1);
                 // ---- scan: running maximum per (lane, token tile) over groups of 4 row tiles.  Rows past K repeat row 0 in
                 // the image (gram_pack_cb_kernel), so no masking: a repeat never beats the row it repeats (lowest group wins ties)
                 float best[A_TT];
@@ -378,6 +394,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                         bgrp[T] = up ? grp : bgrp[T];
                     }
                 }
+                if (li == 1) F_STAMPA(30, 2);
                 // ---- the four lanes (g) of a token hand their (maximum, group) to the token's own lane
                 wave_sync_lds();
 #pragma unroll
@@ -406,43 +423,74 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                     }
                 }
                 if (!okq) { bgr = 0; bg = 0; amb = false; }
-                // ---- the 16 rows behind that maximum, rescored in fp32 (k-ordered fma chain): first maximum wins
-                int brow = 64 * bgr + 4 * bg;
-                float bsc = -INFINITY;
-                auto rescore4 = [&](int r0) {
-                    float f[4 * CP];
-                    if (CEQ) {
-                        const f32x4 *qp = reinterpret_cast<const f32x4 *>(cbf + (size_t)r0 * CP);   // a row quad is CP aligned float4s
+                if (li == 1) F_STAMPA(30, 3);
+                // ---- the 16 rows behind that maximum, rescored in fp32 (k-ordered fma chain, the reference's order): the first
+                // maximum in row order wins.  All 16 scores first (independent chains, every read issued up front), then a
+                // pairwise tournament in row order (the left entry wins ties) instead of a 16-step dependent chain.
+                int brow;
+                {
+                    float sc[16];
+                    int rw[16];
 #pragma unroll
-                        for (int w = 0; w < CP; ++w) {
-                            const f32x4 v = qp[w];
-                            f[4 * w] = v[0]; f[4 * w + 1] = v[1]; f[4 * w + 2] = v[2]; f[4 * w + 3] = v[3];
+                    for (int i = 0; i < 4; ++i) {
+                        const int r0 = 16 * (4 * bgr + i) + 4 * bg;
+                        float f[4 * CP];
+                        if (CEQ) {
+                            const f32x4 *qp = reinterpret_cast<const f32x4 *>(cbf + (size_t)r0 * CP);   // a row quad is CP aligned float4s
+#pragma unroll
+                            for (int w = 0; w < CP; ++w) {
+                                const f32x4 v = qp[w];
+                                f[4 * w] = v[0]; f[4 * w + 1] = v[1]; f[4 * w + 2] = v[2]; f[4 * w + 3] = v[3];
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int j = 0; j < CP; ++j) f[r * CP + j] = j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f;
                         }
-                    } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
+                        for (int r = 0; r < 4; ++r) {
+                            float acc_s = 0.0f;
 #pragma unroll
-                            for (int j = 0; j < CP; ++j) f[r * CP + j] = j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f;
+                            for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(f[r * CP + j], q[j], acc_s);
+                            // rows past K (copies of row 0 in LDS) lose to everything; a NaN score loses too (okq handles NaN rows)
+                            sc[4 * i + r] = (r0 + r < p.K) ? acc_s : -INFINITY;
+                            rw[4 * i + r] = r0 + r;
+                        }
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float sc = 0.0f;
+                    for (int st2 = 1; st2 < 16; st2 *= 2)
 #pragma unroll
-                        for (int j = 0; j < CP; ++j) sc = __builtin_fmaf(f[r * CP + j], q[j], sc);
-                        const bool up = (sc > bsc) && (r0 + r < p.K);
-                        bsc = up ? sc : bsc;
-                        brow = up ? r0 + r : brow;
+                        for (int k = 0; k < 16; k += 2 * st2) {
+                            const bool right = sc[k + st2] > sc[k];       // strict: the earlier row keeps ties
+                            sc[k] = right ? sc[k + st2] : sc[k];
+                            rw[k] = right ? rw[k + st2] : rw[k];
+                        }
+                    brow = rw[0];
+                }
+                // equal maxima in one 64-row block on several lanes (duplicate rows): rescan the block in row order.  Rare: the
+                // wave branches around it
+                if (__builtin_amdgcn_ballot_w64(amb) != 0) {
+                    if (amb) {
+                        float bsc = -INFINITY;
+                        brow = 64 * bgr;
+#pragma unroll 1
+                        for (int r0 = 64 * bgr; r0 < 64 * bgr + 64; r0 += 4) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float acc_s = 0.0f;
+#pragma unroll
+                                for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f, q[j], acc_s);
+                                const bool up = (acc_s > bsc) && (r0 + r < p.K);
+                                bsc = up ? acc_s : bsc;
+                                brow = up ? r0 + r : brow;
+                            }
+                        }
                     }
-                };
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rescore4(16 * (4 * bgr + i) + 4 * bg);
-                if (amb) {   // equal maxima in one 64-row block on several lanes (duplicate rows): rescan the block in row order
-                    brow = 64 * bgr;
-                    bsc = -INFINITY;
-                    for (int r0 = 64 * bgr; r0 < 64 * bgr + 64; r0 += 4) rescore4(r0);
                 }
                 if (!okq) brow = 0;
                 codes[li] = brow;
+                if (li == 1) F_STAMPA(31, 0);
                 // ---- straight-through value (rqae/model.py:218-220)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) {
@@ -450,23 +498,31 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                     const float df = cv - q[j];
                     cvh[li][j] = q[j] + df;
                 }
-                // ---- later levels see the level just applied
-#pragma unroll
-                for (int li2 = li + 1; li2 < GL; ++li2) {
-                    if (FULL || li2 < levels) {
+                if (li == 1) F_STAMPA(31, 1);
+                // ---- later levels see the level just applied.  Every block of the group is staged (zeros past the depth in use), so
+                // no depth checks here: block k+1 is read while block k is multiplied
+                if constexpr (li + 1 < GL) {
+                    float gbr[2][GB];
+                    auto rd = [&](int li2, float (&dst)[GB]) {
                         const float *gb = sgram + (li * GL + li2) * GB;        // broadcast reads
-                        float gbr[GB];
 #pragma unroll
                         for (int w = 0; w < GB / 4; ++w) {
                             const f32x4 v = *reinterpret_cast<const f32x4 *>(gb + 4 * w);
-                            gbr[4 * w] = v[0]; gbr[4 * w + 1] = v[1]; gbr[4 * w + 2] = v[2]; gbr[4 * w + 3] = v[3];
+                            dst[4 * w] = v[0]; dst[4 * w + 1] = v[1]; dst[4 * w + 2] = v[2]; dst[4 * w + 3] = v[3];
                         }
+                    };
+                    rd(li + 1, gbr[0]);
+#pragma unroll
+                    for (int li2 = li + 1; li2 < GL; ++li2) {
+                        const int cur = (li2 - li - 1) & 1;
+                        if (li2 + 1 < GL) rd(li2 + 1, gbr[cur ^ 1]);
 #pragma unroll
                         for (int j = 0; j < CP; ++j)
 #pragma unroll
-                            for (int i = 0; i < CP; ++i) Q[li2][j] = __builtin_fmaf(gbr[j * CP + i], cvh[li][i], Q[li2][j]);
+                            for (int i = 0; i < CP; ++i) Q[li2][j] = __builtin_fmaf(gbr[cur][j * CP + i], cvh[li][i], Q[li2][j]);
                     }
                 }
+                if (li == 1) F_STAMPA(31, 2);
             } else {
                 codes[li] = 0;
 #pragma unroll
@@ -478,12 +534,13 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
             if (lane < 32 && t < tile_end) {
 #pragma unroll
                 for (int li = 0; li < GL; ++li)
-                    if (FULL || li < levels) p.idx[t * levels + li] = (long long)codes[li];
+                    if (li < levels) p.idx[t * levels + li] = (long long)codes[li];
             }
         }
         F_STAMP(4);
         if (p.out == nullptr) {
-            __builtin_amdgcn_s_barrier();     // the union region turns back into the W_in ring
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // LDS turns back into map A
             continue;
         }
 
@@ -518,91 +575,121 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
             wave_sync_lds();
         });
         F_STAMP(5);
-        __builtin_amdgcn_s_barrier();     // the union region turns from the exchange buffers into the W_out ring
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the code stores: the counted waits below start from zero
+        __builtin_amdgcn_s_barrier();     // LDS turns from map B into map C
         F_STAMP(6);
-
         {
             const int nstg = (p.NET + F_ETS - 1) / F_ETS;
-            const bool lo8 = n < 8;
-            // stage e = the W_out fragments of element tiles 4e .. 4e+3, all NKS k-steps: contiguous in the image (NKSC == NKS)
+            // stage e = the W_out fragments of element tiles 4e .. 4e+3, all NKS k-steps (4 pieces per wave)
             auto issueC = [&](int e, int slot) {
                 for (int q = wave; q < F_ETS * NKS; q += F_NW) {
                     int et = e * F_ETS + q / NKS;
                     et = et < p.NET ? et : p.NET - 1;
-                    dma_piece(uniform_ptr(p.wout_img + ((size_t)et * p.NKSC + (q % NKS)) * 512), lds0 + p.off_union + slot * STAGE_C + q * 1024, lane16);
+#ifdef FQ_NOWOUT   /* tools build: every W_out piece re-reads element tile 0 */
+                    et = 0;
+#endif
+                    dma_piece(uniform_ptr(p.wout_img + ((size_t)et * p.NKSC + (q % NKS)) * 512), lds0 + off_wo + slot * STAGE_C + q * 1024, lane16);
                 }
             };
-            // row bases of the 128-byte store rows: lanes n < 8 and n >= 8 of a 16-lane row trade one accumulator (DPP row_ror:8),
-            // so one store instruction writes 128 contiguous bytes (a whole line) for each of 8 tokens
-            float *ob[A_TT][2];
-            bool live[A_TT][2];
-#pragma unroll
-            for (int T = 0; T < A_TT; ++T)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const long long tok = tw0 + 16 * T + 8 * h + (n & 7);
-                    live[T][h] = tok < tile_end;
-                    ob[T][h] = p.out + (size_t)(live[T][h] ? tok : 0) * p.d + 4 * g + (lo8 ? 0 : 16);
-                }
+            for (int q = wave; q < (int)(bias_bytes >> 10); q += F_NW)
+                dma_piece(uniform_ptr(reinterpret_cast<const char *>(p.bias) + (size_t)q * 1024), lds0 + q * 1024, lane16);
             issueC(0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (nstg > 1) issueC(1, 1);
+            constexpr int PCS = (F_ETS * NKS) / F_NW;     // W_out pieces per wave and stage
+            static_assert((F_ETS * NKS) % F_NW == 0, "whole pieces per wave");
+            constexpr int NST = 16;                       // stores per wave and stage pair
+            int slot = 0;
+            f32x4 accC[2 * F_ETS][A_TT];
+            // a wave whose 32 rows and 128-element column blocks all exist issues exactly NST stores per pair (the waits count
+            // them); any other wave predicates its stores and waits for everything instead
+            const bool fullw = (tw0 + 32 <= tile_end) && (p.d % 128 == 0);
+            float *orow = p.out + (size_t)tw0 * p.d;                  // wave-uniform base; lanes add 32-bit offsets
             for (int e0 = 0; e0 < nstg; e0 += 2) {
-                static_for<0, 2>([&](auto sl_c) {
-                    constexpr int SL = decltype(sl_c)::value;
-                    const int e = e0 + SL;
+                static_for<0, 2>([&](auto half_c) {
+                    constexpr int HALF = decltype(half_c)::value;
+                    const int e = e0 + HALF;
                     if (e < nstg) {
-                        // this wave's pieces of stage e landed: the 2 F_ETS stores of the previous stage are the only younger operations
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * F_ETS) : "memory");
-                        __builtin_amdgcn_s_barrier();     // every wave's pieces landed; every wave has left stage e-1
-                        if (e + 1 < nstg) issueC(e + 1, SL ^ 1);
-                        const char *wb = un + SL * STAGE_C + lane * 16;
-#pragma unroll
-                        for (int tp = 0; tp < F_ETS / 2; ++tp) {
-                            const int et = e * F_ETS + 2 * tp;                    // element tiles et, et + 1
-                            const bool et_ok = (lo8 ? et : et + 1) < p.NET;
-                            const int et1 = et + 1 < p.NET ? et + 1 : p.NET - 1, et0c = et < p.NET ? et : p.NET - 1;
-                            const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(sbias + et0c * 16 + 4 * g);
-                            const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(sbias + et1 * 16 + 4 * g);
-                            f32x4 acc0[A_TT], acc1[A_TT];
-#pragma unroll
-                            for (int T = 0; T < A_TT; ++T) { acc0[T] = bias0; acc1[T] = bias1; }
-#pragma unroll
-                            for (int ks = 0; ks < NKS; ++ks) {
-                                const u32x4 a0 = *reinterpret_cast<const u32x4 *>(wb + ((2 * tp) * NKS + ks) * 1024);
-                                const u32x4 a1 = *reinterpret_cast<const u32x4 *>(wb + ((2 * tp + 1) * NKS + ks) * 1024);
-#pragma unroll
-                                for (int T = 0; T < A_TT; ++T) {
-                                    acc0[T] = mfma16(a0, cvB[ks][T], acc0[T]);
-                                    acc1[T] = mfma16(a1, cvB[ks][T], acc1[T]);
-                                }
-                                // keep hipcc from hoisting all 2 NKS fragment reads of the tile pair (64 VGPRs at NKS = 8)
-                                if (ks % 2 == 1) asm volatile("" ::: "memory");
-                            }
-#pragma unroll
-                            for (int T = 0; T < A_TT; ++T) {
-                                f32x4 s0, s1;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float v0 = acc0[T][r], v1 = acc1[T][r];
-                                    const float snd = lo8 ? v1 : v0;
-                                    const float rcv = f32_of((unsigned)__builtin_amdgcn_update_dpp(0, (int)u32_of(snd), 0x128, 0xf, 0xf, false));
-                                    s0[r] = lo8 ? v0 : rcv;    // n < 8: (token n, tile et)      n >= 8: (token n - 8, tile et + 1)
-                                    s1[r] = lo8 ? rcv : v1;    // n < 8: (token n + 8, tile et)  n >= 8: (token n, tile et + 1)
-                                }
-                                // exactly two store instructions per token tile (rows / elements that do not exist go to the dump
-                                // row), so that the wait above can count them
-                                float *dmp = p.dump + ((wave * 4 + 2 * T) & 31) * 256 + lane * 4;     // 32 KiB of dump rows
-                                float *d0 = (live[T][0] && et_ok) ? ob[T][0] + et * 16 : dmp;
-                                float *d1 = (live[T][1] && et_ok) ? ob[T][1] + et * 16 : dmp + 256;
-                                *reinterpret_cast<f32x4 *>(d0) = s0;
-                                *reinterpret_cast<f32x4 *>(d1) = s1;
-                            }
+                        // this wave's pieces of stage e landed.  Younger operations: the pieces of stage e+1 (if it was issued) and the
+                        // stores of one pair
+                        // (D(e) was issued at stage e-2; between then and now exactly one pair stored -- for every e >= 2 --
+                        //  and D(e+1) was issued at stage e-1)
+                        if (!fullw) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ragged wave: its store count is not static
+                        } else if (e + 1 < nstg) {
+                            if (e >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PCS + NST) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PCS) : "memory");
+                        } else {
+                            if (e >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         }
+                        __builtin_amdgcn_s_barrier();     // every wave's pieces landed; every wave has left stage e-1
+                        if (e + 2 < nstg) issueC(e + 2, slot == 0 ? 2 : slot - 1);      // slot (e+2) % 3 was read last in stage e-1
+                        const char *wb = smem + off_wo + slot * STAGE_C + lane * 16;
+                        if (active) {
+                            // the stage's F_ETS x NKS fragments, each feeding A_TT MFMAs: "all reads, then all MFMAs" put in order by
+                            // sched_group_barrier (PF reads ahead, then one read per fragment's MFMAs), as in phase A
+                            constexpr int NFC = F_ETS * NKS, PFC = 6;
+#pragma unroll
+                            for (int t = 0; t < F_ETS; ++t) {
+                                int et = e * F_ETS + t;
+                                et = et < p.NET ? et : p.NET - 1;
+                                const f32x4 bias = *reinterpret_cast<const f32x4 *>(sbias + et * 16 + 4 * g);
+#pragma unroll
+                                for (int T = 0; T < A_TT; ++T) accC[HALF * F_ETS + t][T] = bias;
+                            }
+                            u32x4 frc[NFC];
+#pragma unroll
+                            for (int i = 0; i < NFC; ++i) frc[i] = *reinterpret_cast<const u32x4 *>(wb + i * 1024);
+#pragma unroll
+                            for (int i = 0; i < NFC; ++i) {
+                                const int t = i / NKS, ks = i % NKS;
+#pragma unroll
+                                for (int T = 0; T < A_TT; ++T) accC[HALF * F_ETS + t][T] = mfma16(frc[i], cvB[ks][T], accC[HALF * F_ETS + t][T]);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x100, F_ETS + PFC, 0);      // the bias reads and PFC fragments
+#pragma unroll
+                            for (int i = 0; i < NFC - PFC; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, A_TT, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, PFC * A_TT, 0);
+                        }
+                        slot = slot == 2 ? 0 : slot + 1;
+                    }
+                    if (HALF == 1 && active) {
+                        // ---- the pair's 8 element tiles x 32 tokens: D layout (lane (g, n): token 16T+n, elements 4g..4g+3 of a tile)
+                        // -> rows of 128 elements through LDS, 8 tokens at a time; every store instruction writes 2 rows x 512 bytes.
+                        // A full wave issues exactly NST stores per pair: the waits count them.
+                        const int el0 = e0 * F_ETS * 16 + 4 * (lane & 31);               // this lane's first element
+#pragma unroll
+                        for (int T = 0; T < A_TT; ++T)
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) {
+                                if ((n >> 3) == hh) {
+#pragma unroll
+                                    for (int t = 0; t < 2 * F_ETS; ++t) *reinterpret_cast<f32x4 *>(trb + (n & 7) * F_TRS + t * 64 + 16 * g) = accC[t][T];
+                                }
+                                wave_sync_lds();
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int rr = 2 * i + (lane >> 5);
+                                    const f32x4 v = *reinterpret_cast<const f32x4 *>(trb + rr * F_TRS + (lane & 31) * 16);
+                                    const int row = 16 * T + 8 * hh + rr;
+#ifdef FQ_NOSTORE   /* tools build: the reconstruction is computed and transposed but not stored */
+                                    if (p.n_tokens < 0)
+#else
+                                    if (fullw || (tw0 + row < tile_end && el0 < p.d))
+#endif
+                                        *reinterpret_cast<f32x4 *>(orow + (unsigned)(row * p.d + el0)) = v;
+                                }
+                                wave_sync_lds();
+                            }
                     }
                 });
             }
         }
         F_STAMP(7);
-        __builtin_amdgcn_s_barrier();     // the union region turns back into the W_in ring
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // LDS turns back into map A
     }
 }

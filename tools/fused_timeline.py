@@ -62,16 +62,20 @@ def main():
     ok = st[:, :, :, 0] != 0
     mean = [float(((st[:, :, :, i + 1] - st[:, :, :, i])[ok]).mean()) for i in range(7)]
     print("mean over recorded waves:              " + " ".join(f"{v:7.0f}" for v in mean) + f"  {float(tot[ok].mean()):7.0f}")
-    print("phase A of workgroup 0, tile 1, per chunk: wait+barrier | x loads issue | W DMA issue | multiply (cycles; wave 0 and wave 5)")
+    print("phase A of workgroup 0, tile 1, per chunk: wait+barrier | DMA issue | multiply (cycles; wave 0 and wave 5)")
     for wv in (0, 5):
         rows = []
         for sidx in range(0, 35):
             a = ca[wv, sidx]
             nxt = ca[wv, sidx + 1][0]
-            rows.append((int(a[2] - a[0]), int(a[1] - a[2]), int(a[3] - a[1]), int(nxt - a[3])))
-        print(f"  wave {wv}: " + " ".join(f"{r[0]}|{r[1]}|{r[2]}|{r[3]}" for r in rows[:12]))
+            rows.append((int(a[2] - a[0]), int(a[3] - a[2]), int(nxt - a[3])))
+        print(f"  wave {wv}: " + " ".join(f"{r[0]}|{r[1]}|{r[2]}" for r in rows[:12]))
         arr = np.array(rows[2:])
-        print(f"  wave {wv} mean over chunks 2..34: wait+barrier {arr[:,0].mean():.0f} x-issue {arr[:,1].mean():.0f} dma-issue {arr[:,2].mean():.0f} multiply {arr[:,3].mean():.0f}")
+        print(f"  wave {wv} mean over chunks 2..34: wait+barrier {arr[:,0].mean():.0f} dma-issue {arr[:,1].mean():.0f} multiply {arr[:,2].mean():.0f}")
+    print("phase B, level 1 of workgroup 0 tile 1 (cycles): pieces+exchange | scan | hand-over | rescoring | straight-through | Gram updates")
+    for wv in (0, 3, 5):
+        a, b = ca[wv, 30], ca[wv, 31]
+        print(f"  wave {wv}: {int(a[1]-a[0])} | {int(a[2]-a[1])} | {int(a[3]-a[2])} | {int(b[0]-a[3])} | {int(b[1]-b[0])} | {int(b[2]-b[1])}")
     t0 = st[:, :, 0, 0][ok[:, :, 0]].min()
     print("first tile starts (cycles after the earliest):", sorted(set(int(v - t0) for v in st[:, 0, 0, 0] if v)))
 

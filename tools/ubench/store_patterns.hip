@@ -14,7 +14,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int D = 2304;
 
 #define ST(p, v) do { if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); else *reinterpret_cast<f32x4 *>(p) = v; } while (0)
-template <int MODE_, bool NT = (MODE_ >= 5), int MODE = (MODE_ == 5 ? 1 : MODE_ == 6 ? 4 : MODE_)>
+template <int MODE_, bool NT = (MODE_ == 5 || MODE_ == 6), int MODE = (MODE_ == 5 ? 1 : MODE_ == 6 ? 4 : MODE_)>
 __global__ __launch_bounds__(512) void k(float *out, long long n_tokens, int ngroups_per_wave_stride)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -48,6 +48,10 @@ __global__ __launch_bounds__(512) void k(float *out, long long n_tokens, int ngr
             for (int c0 = 0; c0 < D; c0 += 64)
                 for (int h = 0; h < 8; ++h)
                     *reinterpret_cast<f32x4 *>(out + (t0 + 4 * h + (lane & 3)) * D + c0 + 4 * (lane >> 2)) = v;
+        } else if (MODE == 7) {       // per instruction 2 rows x 512 B
+            for (int c0 = 0; c0 < D; c0 += 128)
+                for (int h = 0; h < 16; ++h)
+                    if (c0 + 4 * (lane & 31) < D) *reinterpret_cast<f32x4 *>(out + (t0 + 2 * h + (lane >> 5)) * D + c0 + 4 * (lane & 31)) = v;
         } else {
             for (int r = 0; r < 32; ++r)
                 for (int c0 = 0; c0 < D; c0 += 256)
@@ -63,8 +67,9 @@ int main(int argc, char **argv)
     hipMalloc(&out, (size_t)n * D * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 7; ++mode) {
-        for (int grid : {256, 512, 1024}) {
+    for (int mode = 0; mode < 8; ++mode) {
+        for (int grid : {32, 64, 128, 256}) {
+            if ((mode == 4 || mode == 6) && grid < 64) continue;   // the slice layout needs 8 XCDs x 8 slices
             float best = 1e9f;
             for (int rep = 0; rep < 5; ++rep) {
                 hipEventRecord(e0);
@@ -76,12 +81,13 @@ int main(int argc, char **argv)
                 case 4: hipLaunchKernelGGL(k<4>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
                 case 5: hipLaunchKernelGGL(k<5>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
                 case 6: hipLaunchKernelGGL(k<6>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
+                case 7: hipLaunchKernelGGL(k<7>, dim3(grid), dim3(512), 0, 0, out, n, 0); break;
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (ms < best) best = ms;
             }
-            printf("mode %d grid %4d: %.3f ms  %.2f TB/s\n", mode, grid, best, (double)n * D * 4 / best / 1e9);
+            printf("mode %d grid %4d: %.3f ms  %.2f TB/s  %.1f GB/s per workgroup\n", mode, grid, best, (double)n * D * 4 / best / 1e9, (double)n * D * 4 / best / 1e6 / grid); fflush(stdout);
         }
     }
     return 0;

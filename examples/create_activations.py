@@ -22,7 +22,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rqae_amd import RQAE, synth  # noqa: E402
+from rqae_amd import RQAE, shards, synth  # noqa: E402
 
 
 class FakeDecoderLayer(torch.nn.Module):
@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--batch-size", type=int, default=4, help="the reference uses 4 (T4 memory)")
     ap.add_argument("--num-quantizers", type=int, default=64, help="pretrained checkpoint: 1024")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--codes-dtype", choices=["int32", "uint16"], default="int32",
+                    help="on-disk dtype of the code shard: int32 as the reference writes, uint16 = half the bytes (K <= 65536)")
     args = ap.parse_args()
 
     dev = torch.device("cuda")
@@ -86,7 +88,8 @@ def main():
     if args.out:
         os.makedirs(os.path.join(args.out, rqae.name), exist_ok=True)
         torch.save(originals, os.path.join(args.out, "000000_original.pt"))
-        torch.save(codes, os.path.join(args.out, rqae.name, "000000.pt"))         # scripts/1:258-261
+        shards.save_codes(os.path.join(args.out, rqae.name, "000000.pt"), codes, dtype=args.codes_dtype,
+                          codebook_rows=rqae.codebook.shape[1])                  # scripts/1:258-261 (int32), or half the bytes
 
 
 if __name__ == "__main__":

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--num-quantizers", type=int, default=1024)
     ap.add_argument("--features", type=int, default=8, help="the reference builds 1024")
     ap.add_argument("--top-k", type=int, default=100)
+    ap.add_argument("--codes", default="", help="a code shard written by create_activations.py (int32 or uint16); default: random codes")
     args = ap.parse_args()
 
     dev = torch.device("cuda")
@@ -45,7 +46,13 @@ def main():
     K = rqae.codebook.shape[1]
 
     g = torch.Generator(device=dev); g.manual_seed(0)
-    indices = torch.randint(0, K, (args.sequences, args.seq_len, nq), device=dev, generator=g, dtype=torch.int32)
+    if args.codes:
+        from rqae_amd import shards
+        indices = shards.load_codes(args.codes).to(dev)          # consumed in its on-disk dtype (uint16 shards are not widened)
+        args.sequences, args.seq_len = indices.shape[0], indices.shape[1]
+        assert indices.shape[2] == nq, f"shard depth {indices.shape[2]} != --num-quantizers {nq}"
+    else:
+        indices = torch.randint(0, K, (args.sequences, args.seq_len, nq), device=dev, generator=g, dtype=torch.int32)
     layers = [l for l in [2, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128, 256, 512, 1023] if l < nq]      # scripts/3:196
     picks = torch.randint(0, args.sequences * args.seq_len, (args.features,), generator=torch.Generator().manual_seed(1))
 

@@ -87,6 +87,9 @@ int rqae_hip_quantize(const float *p, int64_t n, int c, int K, const float *code
  * It is an error if no level is selected (the reference returns None; the host
  * mirror handles that case before calling).
  */
+/* PRECONDITION for every entry point that takes code indices (rqae_hip_decode, rqae_hip_intensity): 0 <= code < K for every
+ * element read.  The kernels gather codebook / table rows by these values without a range check (the reference raises
+ * IndexError); the Python mirror asserts it on the device (rqae_amd/_native.py: check_codes). */
 int rqae_hip_decode(const void *packed, int d, int c, int K, int L, const void *indices,
                     int idx_dtype, int64_t n_tokens, int idx_levels, const uint8_t *level_mask,
                     float *out, void *stream);
@@ -195,6 +198,15 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
 size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels);
 int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
                          int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream);
+/* Which kernels rqae_hip_encode_gram launches (defaults in parentheses; -1 leaves a setting as it is; the environment
+ * variables RQAE_GRAM_FUSED / _PIPE / _PROJ / _RECON set the same at load).  Every combination computes the same function
+ * under the same parity policy; they differ in speed.  Process-wide, not thread-safe against
+ * concurrent encode calls: meant for benchmarks and tests.
+ *   fused       1: one persistent kernel (projection + level chain + reconstruction per 256-token tile)        (0)
+ *   pipe_chunk  > 0: passes of that many tokens, reconstruction of pass i on a second stream beside pass i+1    (0)
+ *   proj        3: LDS-DMA projection kernel, 2: register-pipelined, 1: first form                               (3)
+ *   recon       2: token-stationary reconstruction with 512-byte store rows, 1: weights-stationary               (2) */
+int rqae_hip_gram_configure(int fused, long long pipe_chunk, int proj, int recon);
 int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x,
                                 int x_dtype, int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,
                                 void *stream, float *phase_ms);

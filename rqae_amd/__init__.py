@@ -9,5 +9,6 @@ CPU tensor raises.
 """
 from .model import RQAE  # noqa: F401
 from .feature import Feature, RQAEFeature  # noqa: F401
+from . import ops  # noqa: F401  (registers torch.ops.rqae_hip.{encode, decode, quantize})
 
 __all__ = ["RQAE", "RQAEFeature", "Feature"]

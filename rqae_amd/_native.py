@@ -45,6 +45,7 @@ SYMBOLS = (
     "rqae_hip_gram_workspace_bytes",
     "rqae_hip_encode_gram",
     "rqae_hip_encode_gram_phases",
+    "rqae_hip_gram_configure",
 )
 
 _lib = None
@@ -114,6 +115,8 @@ def lib():
     L.rqae_hip_encode_gram.restype = i
     L.rqae_hip_encode_gram_phases.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.rqae_hip_encode_gram_phases.restype = i
+    L.rqae_hip_gram_configure.argtypes = [i, ctypes.c_longlong, i, i]
+    L.rqae_hip_gram_configure.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"librqae_hip.so ABI {L.rqae_hip_abi_version()} != expected {ABI_VERSION}; rebuild")
@@ -244,6 +247,11 @@ def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels:
     return q, idx
 
 
+def gram_configure(fused: int = -1, pipe_chunk: int = -1, proj: int = -1, recon: int = -1):
+    """Select the kernels of the matrix-core arm (include/rqae_hip.h: rqae_hip_gram_configure); -1 keeps a setting."""
+    _check(lib().rqae_hip_gram_configure(fused, pipe_chunk, proj, recon), "rqae_hip_gram_configure")
+
+
 def encode_gram_phases(gpacked, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True):
     """Measurement only: one encode_gram call timed per kernel -> [ms projection, ms level chain, ms reconstruction]."""
     d, c, K, L_ = dims
@@ -284,6 +292,30 @@ def _mask_arg(level_mask):
     return buf, ctypes.cast(buf, ctypes.c_void_p)
 
 
+_CHECK_ALL_CODES = os.environ.get("RQAE_HIP_CHECK_CODES", "0") not in ("0", "")
+
+
+def check_codes(idx: torch.Tensor, K: int, what: str, always: bool = True):
+    """Device-side assertion that every code is a codebook row (0 <= code < K).
+
+    The kernels gather codebook / table rows by these values (include/rqae_hip.h states the precondition); the reference
+    raises IndexError for such input.  Two reductions and ``torch._assert_async``: no host synchronisation -- a violation
+    surfaces as a device-side assertion at the next synchronising call.  ``always=False`` (the multi-gigabyte code matrices
+    of ``intensity``) checks only small inputs unless RQAE_HIP_CHECK_CODES=1."""
+    if idx.numel() == 0 or not (always or _CHECK_ALL_CODES or idx.numel() <= (1 << 24)):
+        return
+    if idx.dtype == torch.uint16:
+        if K >= 65536:
+            return
+        flat = idx.reshape(-1).view(torch.int16).to(torch.int32) & 0xFFFF if idx.numel() <= (1 << 24) else None
+        if flat is None:
+            return
+        hi, lo = flat.amax(), flat.amin()
+    else:
+        hi, lo = idx.amax(), idx.amin()
+    torch._assert_async((hi < K) & (lo >= 0), f"rqae_amd: {what}: code outside 0..{K - 1} (index out of range for the codebook)")
+
+
 def decode(packed, dims, idx2d: torch.Tensor, level_mask=None) -> torch.Tensor:
     """idx2d [N,NQ] {i64,i32,u16} -> out [N,d] f32 (sum over unmasked levels)."""
     d, c, K, L_ = dims
@@ -294,6 +326,7 @@ def decode(packed, dims, idx2d: torch.Tensor, level_mask=None) -> torch.Tensor:
     out = torch.empty((n, d), dtype=torch.float32, device=idx2d.device)
     if n == 0:
         return out
+    check_codes(idx2d, K, "decode")
     keep, maskp = _mask_arg(level_mask)
     with torch.cuda.device(idx2d.device):
         rc = lib().rqae_hip_decode(packed.data_ptr(), d, c, K, L_, idx2d.data_ptr(), _IDX_DTYPES[idx2d.dtype],
@@ -413,6 +446,7 @@ def intensity(table, w, wcum, M: int, K: int, idx2d: torch.Tensor, layers_dev: t
     n, nq = idx2d.shape
     nl = layers_dev.numel()
     out = torch.empty((n, nl), dtype=torch.float16, device=idx2d.device)
+    check_codes(idx2d[:, :M] if nq > M else idx2d, K, "intensity", always=False)
     if n:
         with torch.cuda.device(idx2d.device):
             rc = lib().rqae_hip_intensity(table.data_ptr(), w.data_ptr(), wcum.data_ptr(), M, K, idx2d.data_ptr(),

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/rqae_hip.h"
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
     char *cbl = smem;
     float *cbf_lds = reinterpret_cast<float *>(smem + imgb);
     char *xch = smem + imgb + cbfb + wave * XCHB;
+    float *sgram = reinterpret_cast<float *>(smem + imgb + cbfb + NW * XCHB);     // the current level group's Gram blocks [li][li2][GB]
 
     // resident codebook image (shared codebooks: one image for every level)
     for (int q = wave; q < p.KTP * NKC; q += NW) glds16(p.cb_img + (size_t)q * 512 + lane * 8, cbl + q * 1024);
@@ -727,6 +729,14 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
     __syncthreads();
 
     const int nlg = (p.levels + GL - 1) / GL;
+    if (!MULTI) {
+        // one level group: its Gram blocks into LDS (broadcast reads instead of dependent L2 round trips in every level)
+        for (int i = tid; i < GL * GL * GB; i += NW * 64) {
+            const int blk = i / GB, li = blk / GL, li2 = blk - li * GL;
+            sgram[i] = (li < p.L && li2 < p.L) ? p.gneg[((size_t)li * p.L + li2) * GB + (i - blk * GB)] : 0.0f;
+        }
+        __syncthreads();
+    }
     const int wq = (lane >> 2) & 3;            // row quad of this lane's token inside its 16-token tile
     for (long long tile = (long long)blockIdx.x * NW + wave; tile < p.ntiles; tile += (long long)gridDim.x * NW) {
         const long long t = tile * 64 + lane;  // < tok_pad
@@ -807,7 +817,6 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
                     for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u32x4 *>(cbl_l + i * NKC * 1024 + lane * 16);
                     for (int grp = 0; grp < ngrp; ++grp) {
                         float mx[4];
-                        const bool tail = (grp == ngrp - 1) && (p.K % 64 != 0);
                         u32x4 a[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) a[i] = an[i];
@@ -824,11 +833,8 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
                             for (int T = 0; T < 4; ++T) s[T] = mfma16(a[i], B[T], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
                             for (int T = 0; T < 4; ++T) {
-                                if (tail) {
-                                    const int r0 = 16 * (grp * 4 + i) + 4 * g;
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) s[T][r] = (r0 + r < p.K) ? s[T][r] : -INFINITY;
-                                }
+                                // (rows past K repeat row 0 in the image -- gram_pack_cb_kernel -- so the last block needs no masking: a repeat
+                                //  never beats the row it repeats, and ties go to the lower row block)
                                 // IEEE-754-2019 maximum (v_maximum3_f32): a NaN score poisons the maximum, which then never
                                 // beats `best`; the level takes index 0 through okq
                                 const float m012 = __builtin_elementwise_maximum(__builtin_elementwise_maximum(s[T][0], s[T][1]), s[T][2]);
@@ -940,7 +946,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
                     for (int li2 = li + 1; li2 < GL; ++li2) {
                         const int l2 = lg * GL + li2;
                         if (l2 < p.levels) {
-                            const float *gb = p.gneg + ((size_t)l * p.L + l2) * GB;
+                            const float *gb = MULTI ? p.gneg + ((size_t)l * p.L + l2) * GB : sgram + (li * GL + li2) * GB;
 #pragma unroll
                             for (int j = 0; j < CP; ++j)
 #pragma unroll
@@ -1169,20 +1175,29 @@ constexpr int B_NW = 8;
 struct Tuning {
     int c_tt;            // reconstruct kernel: 16-token tiles per wave (2: 8 waves per workgroup, 1: 16 waves)
     long long chunk;     // tokens per pass
-    int proj;            // projection kernel: 2 = pipelined form (default), 1 = first form
+    int proj;            // projection kernel: 3 = phase A of the fused kernel (default for 2-byte x), 2 = pipelined register form, 1 = first form
+    int recon;           // reconstruction kernel: 2 = phase C of the fused kernel (default for one level group), 1 = weights-stationary form
+    long long pipe_chunk; // tokens per pass of the pipelined schedule (0: never pipeline)
+    int cap_ab;          // pipelined schedule: CUs for projection + level chain; the reconstruction of the pass before takes the rest
     int fused;           // 1: one persistent kernel where the shape allows it, 0: always the three-kernel form
     int stagger;         // fused kernel: 1 = half first tile on odd workgroups
 };
-const Tuning &tuning()
+Tuning &tuning_mut()
 {
-    static const Tuning t = [] {
+    static Tuning t = [] {
         Tuning v;
         v.chunk = 262144;
         v.c_tt = 2;
-        v.proj = 2;
-        if (const char *e = getenv("RQAE_GRAM_PROJ")) v.proj = atoi(e) == 1 ? 1 : 2;
-        v.fused = 1;
+        v.proj = 3;
+        if (const char *e = getenv("RQAE_GRAM_PROJ")) { const int a = atoi(e); v.proj = a >= 1 && a <= 3 ? a : 3; }
+        v.recon = 2;
+        if (const char *e = getenv("RQAE_GRAM_RECON")) v.recon = atoi(e) == 1 ? 1 : 2;
+        v.fused = 0;
         if (const char *e = getenv("RQAE_GRAM_FUSED")) v.fused = atoi(e) != 0;
+        v.pipe_chunk = 0;       // off: measured slower (profiles/r02_pipeline_trace.txt): the kernels are bound per CU, not by HBM
+        if (const char *e = getenv("RQAE_GRAM_PIPE")) { const long long c = atoll(e); v.pipe_chunk = c <= 0 ? 0 : ((c + 255) & ~255LL); }
+        v.cap_ab = 160;
+        if (const char *e = getenv("RQAE_GRAM_CAP_AB")) { const int c = atoi(e); if (c >= 8) v.cap_ab = c; }
         v.stagger = 0;
         if (const char *e = getenv("RQAE_GRAM_STAGGER")) v.stagger = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
@@ -1191,6 +1206,7 @@ const Tuning &tuning()
     }();
     return t;
 }
+const Tuning &tuning() { return tuning_mut(); }
 
 int device_cus()
 {
@@ -1238,15 +1254,46 @@ size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
 {
     const long long ch = n_tokens < tuning().chunk ? n_tokens : tuning().chunk;
     const long long tp = pad64(ch);
-    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + al256((size_t)nks_recon(g, levels) * tp * 64) + 32768 + (2048 + 8 * 36 * 4) * 8;   // + dump rows + timeline stamps (tools build)
+    // projections, TWO operand-row buffers (the pipelined schedule reconstructs pass i while pass i+1 fills the other one), dump
+    // rows, timeline stamps (tools build)
+    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + 2 * al256((size_t)nks_recon(g, levels) * tp * 64) + 32768 + (2048 + 8 * 36 * 4) * 8;
 }
 
-bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 <= 150 * 1024; }
+bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 + (size_t)g.GL * g.GL * g.GB * 4 <= 158 * 1024; }
 
 // the one-kernel form: one level group, whole chunks of 2 k-steps, everything resident fits the CU's 160 KiB of LDS
 bool fused_shape_ok(const Geom &g, int levels)
 {
     return g.shared_cb && levels <= 8 && g.d % 64 == 0 && g.NKC == 1 && fused_lds_bytes(g.d, g.c, g.K) <= 160 * 1024;
+}
+
+// Second stream for the pipelined schedule (encode_gram_impl): the reconstruction of pass i runs there, beside the projection
+// and the level chain of pass i+1 on the caller's stream.  One per device, created on first use; the events order the
+// two streams (fork from, and join back into, the caller's stream: the call stays asynchronous and capturable).
+struct Side {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, evB[4] = {nullptr, nullptr, nullptr, nullptr}, evC[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = false, tried = false;
+    std::mutex mu;
+};
+Side *side_for_device()
+{
+    static Side sides[64];
+    static std::mutex init_mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    Side &sd = sides[dev];
+    std::lock_guard<std::mutex> lock(init_mu);
+    if (!sd.tried) {
+        sd.tried = true;
+        bool ok = hipStreamCreateWithFlags(&sd.st, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4 && ok; ++i)
+            ok = hipEventCreateWithFlags(&sd.evB[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&sd.evC[i], hipEventDisableTiming) == hipSuccess;
+        sd.ok = ok;
+    }
+    return sd.ok ? &sd : nullptr;
 }
 
 int recon_nks_template(int nks)
@@ -1346,7 +1393,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     const long long tp = pad64(chunk);
     float *P = static_cast<float *>(workspace);
     unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)g.NOG * tp * 16 * sizeof(float)));
-    float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg) + al256((size_t)nks_recon(g, levels) * tp * 64));
+    unsigned *cvimg2 = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(cvimg) + al256((size_t)nks_recon(g, levels) * tp * 64));
+    float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg2) + al256((size_t)nks_recon(g, levels) * tp * 64));
 
     if (tuning().fused && x_dtype != RQAE_X_F32 && fused_shape_ok(g, levels)) {
         FusedParams pf;
@@ -1385,15 +1433,38 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
 #ifdef RQAE_FUSED_QUICK
     return gfail("tools build: only the fused kernel is compiled in");
 #else
-    for (long long t0 = 0; t0 < n_tokens; t0 += chunk) {
-        const long long nt = n_tokens - t0 < chunk ? n_tokens - t0 : chunk;
-        const bool mark = ev && t0 + chunk >= n_tokens;
+    // one pass = projection + level chain (phaseAB) and reconstruction (phaseC) of the tokens [t0, t0 + nt); `ncu` caps the
+    // persistent grids, `cvimg` is the operand-row buffer the two halves share
+    auto phaseAB = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark, bool strict) -> int {
         if (mark) G_TRY(hipEventRecord(ev[0], s));
         // ---- A
         ProjParams pa;
         pa.x = static_cast<const char *>(x) + (size_t)t0 * d * xs;
         pa.win_img = v.win_img; pa.P = P; pa.dump = dump; pa.n_tokens = nt; pa.tok_pad = tp; pa.d = d; pa.NOG = g.NOG; pa.KSA = g.KSA;
-        if (tuning().proj == 2 && g.KSA % 4 == 0) {
+        if (tuning().proj == 3 && x_dtype != RQAE_X_F32 && d % 64 == 0) {
+            FusedParams pf;
+            memset(&pf, 0, sizeof(pf));
+            pf.x = pa.x; pf.win_img = v.win_img; pf.P = P; pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c;
+            pf.levels = levels; pf.L = L; pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET; pf.NKSC = g.NKSC; pf.stagger = 0; pf.dump = dump;
+            pf.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768);
+            long long nb = (nt + F_TILE - 1) / F_TILE;
+            if (nb > ncu) nb = ncu;
+            const int ngf = g.CP == 4 ? FusedGeom<4>::NG : FusedGeom<5>::NG;
+            const size_t lds = g.CP == 4 ? FusedGeom<4>::LDS_A : FusedGeom<5>::LDS_A;
+            for (int ug0 = 0; ug0 < g.NOG; ug0 += ngf) {
+                pf.ug0 = ug0;
+                auto go = [&](auto kern) -> int {
+                    G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pf);
+                    G_TRY(hipGetLastError());
+                    return 0;
+                };
+                int rc;
+                if (g.CP == 4) rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 4, true, 1>);
+                else rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 5, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 5, true, 1>);
+                if (rc) return rc;
+            }
+        } else if (tuning().proj >= 2 && g.KSA % 4 == 0) {
             const unsigned ny = (unsigned)((g.NOG + 2) / 3);
             long long gx = (nt + A2_NW * 16 * A_TT - 1) / (A2_NW * 16 * A_TT);     // persistent: one workgroup per CU walks the tiles
             const long long cap = ncu / ny > 0 ? ncu / ny : 1;
@@ -1445,9 +1516,11 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
         pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
         {
-            const size_t lds = (size_t)g.KTP * g.NKC * 1024 + ((((size_t)K + 64) * c * 4 + 15) & ~(size_t)15) + (size_t)B_NW * g.NKC * 4096;
+            const size_t lds = (size_t)g.KTP * g.NKC * 1024 + ((((size_t)K + 64) * c * 4 + 15) & ~(size_t)15) + (size_t)B_NW * g.NKC * 4096 +
+                               (size_t)g.GL * g.GL * g.GB * 4;
             long long nb = (pb.ntiles + B_NW - 1) / B_NW;
-            if (nb > 2LL * ncu) nb = 2LL * ncu;
+            const long long bcap = strict ? ncu : 2LL * ncu;     // one workgroup fits a CU; the plain schedule queues two rounds
+            if (nb > bcap) nb = bcap;
             auto go = [&](auto kern) -> int {
                 G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(B_NW * 64), lds, s, pb);
@@ -1459,9 +1532,31 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                                      : (multi ? go(gram_levels_kernel<5, B_NW, true>) : go(gram_levels_kernel<5, B_NW, false>));
             if (rc) return rc;
         }
+        return 0;
+    };
+    auto phaseC = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark) -> int {
         if (mark) G_TRY(hipEventRecord(ev[2], s));
         // ---- C
-        if (q_out) {
+        if (q_out && tuning().recon == 2 && levels <= 8 && d % 16 == 0 &&
+            pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW <= 160 * 1024) {
+            FusedParams pf;
+            memset(&pf, 0, sizeof(pf));
+            pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = q_out + (size_t)t0 * d;
+            pf.cvimg = cvimg; pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c; pf.levels = levels; pf.L = L;
+            pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET; pf.NKSC = g.NKSC; pf.stagger = 0; pf.dump = dump; pf.nks_live = nks;
+            pf.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768);
+            long long nb = (nt + F_TILE - 1) / F_TILE;
+            if (nb > ncu) nb = ncu;
+            const size_t lds = pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pf);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            const int rc = g.CP == 4 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 2>) : go(gram_fused_kernel<RQAE_X_BF16, 5, true, 2>);
+            if (rc) return rc;
+        } else if (q_out) {
             RecParams pc;
             pc.wout_img = v.wout_img; pc.bias = v.bias_prefix + (size_t)(levels - 1) * d; pc.cvimg = cvimg;
             pc.out = q_out + (size_t)t0 * d;
@@ -1501,6 +1596,41 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             if (rc) return rc;
         }
         if (mark) G_TRY(hipEventRecord(ev[3], s));
+        return 0;
+    };
+    // ---- pipelined schedule: passes of pipe_chunk tokens; the reconstruction of pass i (HBM writes) runs on the second stream
+    // beside the projection (HBM reads) and the level chain (matrix cores, no memory traffic) of pass i+1.  Every workgroup of
+    // these kernels fills a CU's LDS, so capped grids split the CUs between the two streams.
+    if (!ev && q_out && tuning().pipe_chunk > 0 && n_tokens > tuning().pipe_chunk && tuning().pipe_chunk <= tp) {
+        Side *sd = side_for_device();
+        if (sd) {
+            const long long pch = tuning().pipe_chunk;
+            int cap_ab = tuning().cap_ab < ncu - 8 ? tuning().cap_ab : ncu - 8;
+            if (cap_ab < 8) cap_ab = 8;
+            const int cap_c = ncu - cap_ab;
+            std::lock_guard<std::mutex> lock(sd->mu);
+            G_TRY(hipEventRecord(sd->fork, s));
+            G_TRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
+            int i = 0;
+            for (long long t0 = 0; t0 < n_tokens; t0 += pch, ++i) {
+                const long long nt = n_tokens - t0 < pch ? n_tokens - t0 : pch;
+                unsigned *cvb = (i & 1) ? cvimg2 : cvimg;
+                if (i >= 2) G_TRY(hipStreamWaitEvent(s, sd->evC[(i - 2) & 3], 0));     // the buffer's last reader
+                if (int rc = phaseAB(t0, nt, s, cap_ab, cvb, false, true)) return rc;
+                G_TRY(hipEventRecord(sd->evB[i & 3], s));
+                G_TRY(hipStreamWaitEvent(sd->st, sd->evB[i & 3], 0));
+                if (int rc = phaseC(t0, nt, sd->st, cap_c, cvb, false)) return rc;
+                G_TRY(hipEventRecord(sd->evC[i & 3], sd->st));
+            }
+            G_TRY(hipStreamWaitEvent(s, sd->evC[(i - 1) & 3], 0));                      // join
+            return 0;
+        }
+    }
+    for (long long t0 = 0; t0 < n_tokens; t0 += chunk) {
+        const long long nt = n_tokens - t0 < chunk ? n_tokens - t0 : chunk;
+        const bool mark = ev && t0 + chunk >= n_tokens;
+        if (int rc = phaseAB(t0, nt, s, ncu, cvimg, mark, false)) return rc;
+        if (int rc = phaseC(t0, nt, s, ncu, cvimg, mark)) return rc;
     }
     return 0;
 #endif
@@ -1514,6 +1644,16 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
 {
     return encode_gram_impl(packed, d, c, K, L, codebook_shared, x, x_dtype, n_tokens, levels, q_out, indices, workspace, stream,
                             nullptr);
+}
+
+int rqae_hip_gram_configure(int fused, long long pipe_chunk, int proj, int recon)
+{
+    Tuning &t = tuning_mut();
+    if (fused >= 0) t.fused = fused != 0;
+    if (pipe_chunk >= 0) t.pipe_chunk = pipe_chunk == 0 ? 0 : ((pipe_chunk + 255) & ~255LL);
+    if (proj >= 1 && proj <= 3) t.proj = proj;
+    if (recon >= 1 && recon <= 2) t.recon = recon;
+    return 0;
 }
 
 int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,

@@ -39,6 +39,12 @@ struct FusedParams {
     long long n_tokens;
     int d, K, KTP, c, levels, L, KSA, NOG, NET, NKSC;
     int stagger;               // 1: the first tile of every odd workgroup is a half tile (ftile_off)
+    // the single-phase forms (MODE 1 / 2 below) exchange the intermediates of the three-kernel path with gram_levels_kernel:
+    float *P;                  // MODE 1 writes the projections [NOG][tok_pad][16]
+    const unsigned *cvimg;     // MODE 2 reads the reconstruction operand rows [k-step][tok_pad][16 dwords]
+    long long tok_pad;
+    int ug0;                   // MODE 1: first projection group of this launch (NG groups per launch)
+    int nks_live;              // MODE 2: k-steps the levels in use fill (the rest are zero)
 };
 
 constexpr int F_NW = 8;                 // waves per workgroup
@@ -120,7 +126,9 @@ __device__ __forceinline__ void wave_sync_lds()
 #endif
 
 // CEQ: c == CP (codebook rows are CP floats apart: aligned float4 row quads)
-template <int XT, int CP, bool CEQ>
+// MODE 0: all three phases.  MODE 1: phase A alone (projections to global memory: the first kernel of the three-kernel
+// path).  MODE 2: phase C alone (operand rows from global memory: its third kernel).  Same code, same bits.
+template <int XT, int CP, bool CEQ, int MODE = 0>
 __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 {
     using G = FusedGeom<CP>;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
         for (int u = 0; u < NG; ++u)
 #pragma unroll
             for (int T = 0; T < A_TT; ++T) acc[u][T] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
+        if constexpr (MODE != 2) {
             // Piece pc of a chunk = rows 8 pc .. 8 pc + 7 of the wave x 128 bytes; lane i = (row r = i >> 3, slot jj = i & 7)
             // lands at piece + 16 i and fetches the row's 16-byte chunk jj ^ r: LDS row r holds chunk j at slot j ^ r, and the
             // operand reads below (lane (g, n): row n, chunk 4k + g) touch 16 different bank groups per 16-lane read group.
@@ -207,7 +215,10 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 #else
                     const int ks = cc * KC + k;          // < KSA: the host sends only d % (32 KC) == 0 here
 #endif
-                    dma_piece(uniform_ptr(p.win_img + (((size_t)ks * p.NOG) * 3 + f) * 512), lds0 + slot * STAGE_A + (k * FPK + f) * 1024, lane16);
+                    int fu = f / 3;                      // groups past the last one repeat it (MODE 1, never stored)
+                    fu = (MODE == 1 ? p.ug0 : 0) + fu;
+                    fu = fu < p.NOG ? fu : p.NOG - 1;
+                    dma_piece(uniform_ptr(p.win_img + (((size_t)ks * p.NOG + fu) * 3 + (f % 3)) * 512), lds0 + slot * STAGE_A + (k * FPK + f) * 1024, lane16);
                 }
             };
             issue(0, 0);
@@ -267,6 +278,21 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated groups past the last chunk
         }
         F_STAMP(1);
+        if constexpr (MODE == 1) {
+            // D layout: lane (g, n) holds outputs 4g..4g+3 of token 16T+n of group u
+#pragma unroll
+            for (int u = 0; u < NG; ++u)
+#pragma unroll
+                for (int T = 0; T < A_TT; ++T) {
+                    const long long tok = tw0 + 16 * T + n;
+                    if (tok < tile_end && p.ug0 + u < p.NOG) *reinterpret_cast<f32x4 *>(p.P + (((size_t)(p.ug0 + u) * p.tok_pad + tok) * 16 + 4 * g)) = acc[u][T];
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // the rings are free for the next tile
+            continue;
+        }
+        u32x4 cvB[NKS][A_TT];
+        if constexpr (MODE == 0) {
         __builtin_amdgcn_s_barrier();    // LDS turns from map A into map B
         F_STAMP(2);
         // ---- map B tables: codebook image + fp32 codebook by LDS-DMA, Gram blocks of the level group by the threads
@@ -547,7 +573,6 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
         // =========================================================================================== phase C
         // ---- cv pieces of the wave's tokens as B operands: slot of (level li, component j, term) = (li CP + j) 6 + term,
         // dword (li CP + j) 3 + {0: hi|mid, 1: hi|lo, 2: hi|mid}; two k-steps (32 dwords per token) per trip through LDS
-        u32x4 cvB[NKS][A_TT];
         static_for<0, (NKS + 1) / 2>([&](auto r_c) {
             constexpr int R = decltype(r_c)::value;
             unsigned dwr[32];
@@ -578,6 +603,21 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the code stores: the counted waits below start from zero
         __builtin_amdgcn_s_barrier();     // LDS turns from map B into map C
         F_STAMP(6);
+        }   // MODE == 0
+        if constexpr (MODE == 2) {
+            // operand rows written by gram_levels_kernel: lane (g, n) takes dwords 4g..4g+3 of token 16T+n for every k-step
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int T = 0; T < A_TT; ++T) {
+                    long long tok = tw0 + 16 * T + n;
+                    tok = tok < tile_end ? tok : tile_end - 1;
+                    const int kc = ks < p.nks_live ? ks : p.nks_live - 1;      // k-steps past the depth in use: any row (their weights are zeroed below)
+                    cvB[ks][T] = *reinterpret_cast<const u32x4 *>(p.cvimg + ((size_t)kc * p.tok_pad + tok) * 16 + 4 * g);
+                    if (ks >= p.nks_live) cvB[ks][T] = u32x4{0u, 0u, 0u, 0u};
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         {
             const int nstg = (p.NET + F_ETS - 1) / F_ETS;
             // stage e = the W_out fragments of element tiles 4e .. 4e+3, all NKS k-steps (4 pieces per wave)

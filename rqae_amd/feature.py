@@ -125,3 +125,17 @@ class RQAEFeature:
 
     def save(self, file_path: str):
         np.savez(file_path, **{k: v for k, v in self.__dict__.items() if k not in ("rqae", "_prepared")})
+
+    @classmethod
+    def load(cls, file_path: str):
+        """Read back what ``save`` wrote (rqae/feature.py:142-153): every stored array that holds exactly one element is
+        unwrapped to the Python object (``ndarray.item()``), anything longer stays an array; ``explanations`` comes back
+        as a list of ``str``.  The model is not part of the file: call ``load_model`` before ``intensity``."""
+        stored = np.load(file_path, allow_pickle=True)
+        fields = {}
+        for key in stored.files:
+            value = stored[key]
+            fields[key] = [str(text) for text in value] if key == "explanations" and value.ndim > 0 else value
+            if value.size == 1:
+                fields[key] = value.item()
+        return cls(**fields)

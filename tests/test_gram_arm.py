@@ -130,19 +130,21 @@ def test_gram_empty_batch_and_errors():
         assert torch.equal(auto(x)[1], exact(x)[1])
 
 
-def test_gram_nonfinite_and_zero_rows():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gram_nonfinite_and_zero_rows(dtype):
     """Zero / NaN / inf rows take index 0 at the level where the projection is not a finite non-zero vector
-    (torch.argmax over NaNs, rqae/model.py:182,188); neighbours are unaffected."""
+    (torch.argmax over NaNs, rqae/model.py:182,188); neighbours are unaffected.  (fp32 rows go through the register
+    projection kernel, 2-byte rows through the LDS-DMA one.)"""
     cfg = synth.CONFIGS["C2"]
     w = synth.weights(5, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
     m = make_model(cfg, w, "gram")
     x = synth.activations(11, 200, cfg["dim"])
-    clean = run(m, x, torch.float32)[1]
+    clean = run(m, x, dtype)[1]
     x2 = x.copy()
     x2[17] = np.nan
     x2[64, 5] = np.inf
     x2[130] = 0.0          # zero row: the projection is b_in (finite), nothing special
-    _, idx, _ = run(m, x2, torch.float32)
+    _, idx, _ = run(m, x2, dtype)
     keep = np.ones(200, bool); keep[[17, 64, 130]] = False
     assert np.array_equal(idx[keep], clean[keep])
     assert (idx[17] == 0).all() and (idx[64] == 0).all()
@@ -255,3 +257,82 @@ def test_arm_auto_switches_on_batch_size():
     with torch.inference_mode():
         assert torch.equal(auto(small)[0], exact(small)[0])      # bit-equal reconstruction = the exact arm ran
         assert torch.equal(auto(large)[0], gram(large)[0])
+
+
+@pytest.mark.parametrize("variant", ["fused", "pipelined", "first kernels"])
+def test_gram_kernel_variants(variant):
+    """Every kernel selection of the arm (rqae_hip_gram_configure) under the same Tier-2 bar, at a size that spans several
+    tiles / passes and a ragged end; the defaults are what every other test in this file runs."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    n = 70000 + 77
+    x = np.concatenate([synth.activations(900 + i, min(32768, n - s), cfg["dim"]) for i, s in enumerate(range(0, n, 32768))])
+    sel = np.unique(np.concatenate([np.arange(0, n, 61), np.arange(n - 300, n)]))
+    try:
+        if variant == "fused":
+            _native.gram_configure(fused=1)
+        elif variant == "pipelined":
+            _native.gram_configure(pipe_chunk=16384)
+        else:
+            _native.gram_configure(proj=2, recon=1)
+        for dt in (torch.bfloat16, torch.float16, torch.float32):
+            q, idx, xs = run(m, x, dt)
+            check_tier2(xs[sel], w, q[sel], idx[sel])
+            with torch.inference_mode():
+                only = m.encode(torch.from_numpy(x).to(DEV).to(dt).view(1, n, -1))
+            assert np.array_equal(only.cpu().numpy().reshape(n, -1), idx)
+        q3, i3, xs = run(m, x[:5000], torch.bfloat16, max_layers=3)
+        check_tier2(xs, w, q3, i3, levels=3)
+    finally:
+        _native.gram_configure(fused=0, pipe_chunk=0, proj=3, recon=2)
+
+
+def test_operators_match_the_module_bit_for_bit():
+    """torch.ops.rqae_hip.{encode, decode, quantize} against RQAE.forward / decode / quantize (exact arm)."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(21, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "exact")
+    x = torch.from_numpy(synth.activations(5, 777, cfg["dim"])).to(DEV)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in w.items()}
+    with torch.inference_mode():
+        q, idx = m(x.view(1, 777, -1))
+        q2, idx2 = torch.ops.rqae_hip.encode(x, t["w_in"], t["b_in"], t["codebook"], t["w_out"], t["b_out"], 99, True)
+        assert torch.equal(q2, q[0]) and torch.equal(idx2, idx[0])
+        q3, idx3 = torch.ops.rqae_hip.encode(x.to(torch.bfloat16), t["w_in"], t["b_in"], t["codebook"], t["w_out"], t["b_out"], 3, False)
+        assert q3.numel() == 0 and torch.equal(idx3, m.encode(x.to(torch.bfloat16).view(1, 777, -1), max_layers=3)[0])
+        d0 = m.decode(idx)
+        d1 = torch.ops.rqae_hip.decode(idx[0], t["codebook"][0], t["w_out"], t["b_out"], torch.empty(0, dtype=torch.bool, device=DEV))
+        assert torch.equal(d1, d0[0])
+        mask = torch.tensor([True, False, True, False, False, False, False, True], device=DEV)
+        d2 = torch.ops.rqae_hip.decode(idx[0], t["codebook"][0], t["w_out"], t["b_out"], mask)
+        assert torch.equal(d2, m.decode(idx, layers=[0, 2, 7])[0])
+        p = torch.randn(300, cfg["codebook_dim"], device=DEV)
+        cv, k = m.quantize(p, 2)
+        cv2, k2 = torch.ops.rqae_hip.quantize(p, t["codebook"][2])
+        assert torch.equal(cv, cv2) and torch.equal(k, k2)
+
+
+def test_out_of_range_codes_assert_on_the_device():
+    """decode with a code >= K: the reference raises IndexError; here the range check is a device-side assertion (no host
+    synchronisation on the good path).  A failed device assertion poisons the process, so this runs in a child."""
+    import subprocess
+    import sys
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from rqae_amd import RQAE\n"
+        "m = RQAE(dim=256, codebook_dim=4, codebook_size=4, num_quantizers=2).eval().to('cuda:0')\n"
+        "ok = torch.zeros(1, 8, 2, dtype=torch.long, device='cuda:0')\n"
+        "m.decode(ok); torch.cuda.synchronize(); print('good codes pass', flush=True)\n"
+        "bad = ok.clone(); bad[0, 3, 1] = 256\n"
+        "try:\n"
+        "    m.decode(bad); torch.cuda.synchronize(); print('NOT CAUGHT', flush=True)\n"
+        "except Exception as e:\n"
+        "    print('caught', type(e).__name__, flush=True)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "good codes pass" in r.stdout, r.stdout + r.stderr
+    assert "NOT CAUGHT" not in r.stdout and ("caught" in r.stdout or r.returncode != 0), r.stdout + r.stderr

@@ -368,7 +368,7 @@ class FakeGemma2LLM:
             original_hidden_states.float().pow(2).mean(-1, keepdim=True) + 1e-6)
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_fused_gemma_hook(dtype):
     """norm before / denorm + BOS skip + in-place write-back after forward as HIP kernels.
     Bit-exact against the oracle's restatement; against the torch ops of the generic hook to rounding."""
@@ -393,6 +393,9 @@ def test_fused_gemma_hook(dtype):
     hs_f, st_f = run(True)
     hs_g, st_g = run(False)
     assert set(st_f) == set(st_g) == {"original", "normed", "quantized", "indices", "new"}
+    # `original` is a copy taken BEFORE the in-place patch (rqae/model.py:278 clones it), also when the LLM runs in fp32
+    assert torch.equal(st_f["original"], hs0.float()) and torch.equal(st_g["original"], hs0.float())
+    assert st_f["original"].data_ptr() != hs_f.data_ptr()
     # --- oracle restatement: bit for bit
     hs_np = hs0.float().cpu().numpy()
     normed_o, rs_o = oracle.gemma_norm_canonical(hs_np, nw)
@@ -407,8 +410,10 @@ def test_fused_gemma_hook(dtype):
     assert torch.equal(hs_f[:, 0], hs0[:, 0])                                     # BOS rows untouched
     # --- the generic (torch-op) hook: same thing to rounding
     assert rel_err(st_f["normed"].cpu().numpy(), st_g["normed"].cpu().numpy()) < 1e-6
+    # (the fused norm sums the squares in the canonical order, torch in its own: `normed` can differ in the last bit, and a
+    #  token at a near-tie then takes the other row -- none does on this fixture)
     same = (st_f["indices"] == st_g["indices"]).all(-1).float().mean().item()
-    assert same >= 0.98                                                           # normed differs in the last bit
+    assert same == 1.0
     ok = (st_f["indices"] == st_g["indices"]).all(-1)
     assert rel_err(st_f["new"][ok].cpu().numpy(), st_g["new"][ok].cpu().numpy()) < 1e-5
     # --- without a store nothing is cloned, the patch still happens; replace=False leaves hs alone
@@ -831,3 +836,50 @@ def test_pretrained_depth_end_to_end():
     assert np.array_equal(dec[0].cpu().numpy(), oracle.decode(idx_o, w))
     assert np.array_equal(dec_sub[0].cpu().numpy(), oracle.decode(idx_o, w, layers=[0, 5, 700, 1023]))
     assert len(np.unique(idx)) > 300                      # deep levels still spread over the codebook
+
+
+def test_c5_shape_at_its_stated_depth():
+    """BASELINE configs[4]'s shape at its stated depth (d 2304, K 4096 = 8^4, depth 32) on the exact arm: a batch that fills
+    the chip, the oracle on a strided sample, properties on all of it.  (The reduced-precision distance the config names is
+    not built: DESIGN.md section 6.)"""
+    cfg = dict(synth.CONFIGS["C5"])
+    assert cfg["num_quantizers"] == 32
+    w = synth.weights(55, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    n = 16384
+    x = synth.activations(56, n, cfg["dim"])
+    xt = torch.from_numpy(x).to(DEV).view(1, n, -1)
+    with torch.inference_mode():
+        q, idx = m(xt)
+        assert idx.shape == (1, n, 32) and int(idx.max()) < 4096 and int(idx.min()) >= 0
+        assert torch.equal(m(xt, max_layers=7)[1], idx[..., :7])
+        dec = m.decode(idx)
+        assert float((dec - q).abs().max() / q.abs().max()) < 2e-6
+    sel = np.arange(0, n, 53)
+    q_o, idx_o = oracle.forward(x[sel], w)
+    assert np.array_equal(idx[0, sel].cpu().numpy(), idx_o)
+    assert np.array_equal(q[0, sel].cpu().numpy(), q_o)
+
+
+def test_c4_shape_at_its_stated_depth_and_a_full_batch():
+    """BASELINE configs[3] as stated (d 3584, K 8192 = 2^13, c 13, depth 16) on 65 536 tokens: the codebook (416 KB) is
+    scanned through LDS in chunks; the oracle on a strided sample, properties on all of it."""
+    cfg = dict(synth.CONFIGS["C4"])
+    assert cfg["num_quantizers"] == 16
+    w = synth.weights(44, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    n = 65536
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    x = torch.randn(n, cfg["dim"], device=DEV, generator=g)
+    x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)
+    with torch.inference_mode():
+        q, idx = m(x.view(1, n, -1))
+        assert idx.shape == (1, n, 16) and int(idx.max()) < 8192 and int(idx.min()) >= 0
+        qa, ia = m(x[:20001].view(1, -1, cfg["dim"]))
+        assert torch.equal(ia[0], idx[0, :20001]) and torch.equal(qa[0], q[0, :20001])
+        dec = m.decode(idx)
+        assert float((dec - q).abs().max() / q.abs().max()) < 2e-6
+    sel = np.arange(0, n, 1021)
+    q_o, idx_o = oracle.forward(x[sel].cpu().numpy(), w)
+    assert np.array_equal(idx[0, sel].cpu().numpy(), idx_o)
+    assert np.array_equal(q[0, sel].cpu().numpy(), q_o)

@@ -175,3 +175,94 @@ def test_feature_mirror_host_side():
     assert h.layers == [1, 5] and torch.equal(h.center, g.center) and h._prepared is None
     t = g.to_feature(1)
     assert isinstance(t, Feature) and t.activations == []
+
+
+def test_feature_save_load_round_trip(tmp_path):
+    """RQAEFeature.save / load (rqae/feature.py:139-153): what scripts 4-7 read back."""
+    import numpy as np
+
+    from rqae_amd import RQAEFeature
+
+    f = RQAEFeature(id="tok-17", explanations=["first", "second"], scores=[{"a": 1.0}, {"b": 2.0}], model="rqae-x",
+                    num_quantizers=6, dim=4, layers=[1, 5], layer_weights=np.linspace(0.5, 1.0, 6), center=np.arange(6))
+    path = str(tmp_path / "feat.npz")
+    f.save(path)
+    g = RQAEFeature.load(path)
+    assert g.id == "tok-17" and g.model == "rqae-x" and g.num_quantizers == 6 and g.dim == 4
+    assert g.explanations == ["first", "second"] and all(isinstance(e, str) for e in g.explanations)
+    assert list(g.layers) == [1, 5] and torch.equal(g.center, f.center) and torch.equal(g.layer_weights, f.layer_weights)
+    assert list(g.scores) == [{"a": 1.0}, {"b": 2.0}]
+    one = RQAEFeature(id=3, explanations=["only"], num_quantizers=2, dim=4)     # one-element arrays unwrap, as ndarray.item() does
+    one.save(path)
+    h = RQAEFeature.load(path)
+    assert h.explanations == "only" and h.num_quantizers == 2
+
+
+def test_from_pretrained_reads_the_hub_layout(tmp_path, monkeypatch):
+    """RQAE.from_pretrained (rqae/model.py:75-99) against a local copy of the hub layout: <folder>/config.json +
+    <folder>/model.safetensors, strict state-dict load, the name built from the config."""
+    import json
+
+    import huggingface_hub
+    from safetensors.torch import save_file
+
+    cfg = dict(dim=32, codebook_dim=3, codebook_size=3, num_quantizers=4, quantization_method="round_fsq")
+    src = RQAE(**cfg)
+    with torch.no_grad():
+        for p in src.layers.parameters():
+            p.uniform_(-0.3, 0.3)
+    folder = tmp_path / "gemma-2-2b"
+    folder.mkdir()
+    save_file({k: v.contiguous() for k, v in src.state_dict().items()}, str(folder / "model.safetensors"))
+    (folder / "config.json").write_text(json.dumps(cfg))
+    asked = []
+
+    def fake_download(repo_id, filename, **kw):
+        asked.append((repo_id, filename))
+        return str(tmp_path / filename)
+
+    monkeypatch.setattr(huggingface_hub, "hf_hub_download", fake_download)
+    m = RQAE.from_pretrained("google/gemma-2-2b")                       # alias of harish-kamath/rqae/gemma-2-2b
+    assert asked == [("harish-kamath/rqae", "gemma-2-2b/model.safetensors"), ("harish-kamath/rqae", "gemma-2-2b/config.json")]
+    assert m.name == "rqae-rqae-round_fsq-cbd3-cbs3-nq4" and m.num_quantizers == 4 and m.codebook.shape == (4, 27, 3)
+    for k, v in src.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v), k
+    bad = dict(cfg, num_quantizers=5)
+    (folder / "config.json").write_text(json.dumps(bad))
+    with pytest.raises(RuntimeError):                                    # strict load: a checkpoint of another depth is refused
+        RQAE.from_pretrained("harish-kamath/rqae/gemma-2-2b")
+
+
+def test_operators_are_registered():
+    """torch.ops.rqae_hip.{encode, decode, quantize} exist with fake implementations (shape/dtype inference on meta)."""
+    import rqae_amd  # noqa: F401
+
+    x = torch.empty(5, 16, device="meta")
+    w_in, b_in = torch.empty(3, 2, 16, device="meta"), torch.empty(3, 2, device="meta")
+    cb, w_out, b_out = torch.empty(3, 9, 2, device="meta"), torch.empty(3, 16, 2, device="meta"), torch.empty(3, 16, device="meta")
+    q, idx = torch.ops.rqae_hip.encode(x, w_in, b_in, cb, w_out, b_out, 2, True)
+    assert q.shape == (5, 16) and q.dtype == torch.float32 and idx.shape == (5, 2) and idx.dtype == torch.int64
+    q, idx = torch.ops.rqae_hip.encode(x, w_in, b_in, cb, w_out, b_out, 99, False)
+    assert q.numel() == 0 and idx.shape == (5, 3)
+    out = torch.ops.rqae_hip.decode(torch.empty(5, 3, dtype=torch.int64, device="meta"), cb[0], w_out, b_out, torch.empty(0, dtype=torch.bool, device="meta"))
+    assert out.shape == (5, 16)
+    cv, k = torch.ops.rqae_hip.quantize(torch.empty(7, 2, device="meta"), cb[0])
+    assert cv.shape == (7, 2) and k.shape == (7,) and k.dtype == torch.int64
+
+
+def test_code_shards_round_trip(tmp_path):
+    """The reference's int32 shard and the uint16 shard (half the bytes) hold the same codes; both load without pickle."""
+    from rqae_amd import shards
+
+    codes = torch.randint(0, 625, (6, 16, 40), dtype=torch.int64)
+    p32, p16 = str(tmp_path / "a.pt"), str(tmp_path / "b.pt")
+    shards.save_codes(p32, codes, dtype="int32")
+    shards.save_codes(p16, codes, dtype="uint16", codebook_rows=625)
+    a, b = shards.load_codes(p32), shards.load_codes(p16)
+    assert a.dtype == torch.int32 and b.dtype == torch.uint16 and a.shape == b.shape == codes.shape
+    assert torch.equal(a.long(), codes) and torch.equal(b.to(torch.int32).long(), codes)
+    assert os.path.getsize(p16) < 0.6 * os.path.getsize(p32)
+    with pytest.raises(ValueError):
+        shards.save_codes(p16, codes + 70000, dtype="uint16")
+    with pytest.raises(ValueError):
+        shards.save_codes(p16, codes, dtype="int8")

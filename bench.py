@@ -230,11 +230,23 @@ def main():
                     "mfma_bf16_TFLOPs": tok_per_s_kernel * GRAM_MFMA_FLOPS_PER_TOKEN / 1e12,
                     "mfma_bf16_frac": tok_per_s_kernel * GRAM_MFMA_FLOPS_PER_TOKEN / 1e12 / PEAK_BF16_TFLOPS,
                     "algorithmic_fp32_TFLOPs": tok_per_s_kernel * FLOPS_PER_TOKEN / 1e12}
+            try:    # MFMA-busy and per-kernel counters: measured by tools/pmc.py for THIS build (same source hash) or absent
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+                if traffic is not None:
+                    roof["mfma_busy_frac_by_kernel"] = {k: round(v["mfma_busy_frac"], 3) for k, v in pj["kernels"].items() if "mfma_busy_frac" in v}
+            except Exception:
+                pass
             try:
                 with torch.inference_mode():
                     ph = [_native.encode_gram_phases(model.gram_packed_weights(), model._dims(), x.view(tokens, -1), L,
                                                      want_recon=not args.codes_only) for _ in range(5)]
                 roof["kernel_ms"] = dict(zip(["project", "levels", "reconstruct"], [float(np.median(v)) for v in zip(*ph)]))
+                if not args.codes_only:
+                    # the dominant kernel on its own: the reconstruction writes 4 d bytes per token (its algorithmic bytes)
+                    rms = roof["kernel_ms"]["reconstruct"]
+                    rg = tokens * 4.0 * D / (rms * 1e-3) / 1e9
+                    roof["dominant_kernel"] = {"name": "reconstruct (gram_fused_kernel<.., 2>)", "ms": rms, "algorithmic_bytes": tokens * 4 * D,
+                                               "achieved_GBs": rg, "frac": rg / PEAK_HBM_GBS}
             except Exception as e:  # measurement extra only
                 roof["kernel_ms"] = f"unavailable: {e}"
         else:

@@ -46,6 +46,7 @@ SYMBOLS = (
     "rqae_hip_encode_gram",
     "rqae_hip_encode_gram_phases",
     "rqae_hip_gram_configure",
+    "rqae_hip_gram_configure_levels",
 )
 
 _lib = None
@@ -117,6 +118,8 @@ def lib():
     L.rqae_hip_encode_gram_phases.restype = i
     L.rqae_hip_gram_configure.argtypes = [i, ctypes.c_longlong, i, i]
     L.rqae_hip_gram_configure.restype = i
+    L.rqae_hip_gram_configure_levels.argtypes = [i]
+    L.rqae_hip_gram_configure_levels.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"librqae_hip.so ABI {L.rqae_hip_abi_version()} != expected {ABI_VERSION}; rebuild")
@@ -247,9 +250,10 @@ def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels:
     return q, idx
 
 
-def gram_configure(fused: int = -1, pipe_chunk: int = -1, proj: int = -1, recon: int = -1):
-    """Select the kernels of the matrix-core arm (include/rqae_hip.h: rqae_hip_gram_configure); -1 keeps a setting."""
+def gram_configure(fused: int = -1, pipe_chunk: int = -1, proj: int = -1, recon: int = -1, lean_levels: int = -1):
+    """Select the kernels of the matrix-core arm (include/rqae_hip.h: rqae_hip_gram_configure[_levels]); -1 keeps a setting."""
     _check(lib().rqae_hip_gram_configure(fused, pipe_chunk, proj, recon), "rqae_hip_gram_configure")
+    _check(lib().rqae_hip_gram_configure_levels(lean_levels), "rqae_hip_gram_configure_levels")
 
 
 def encode_gram_phases(gpacked, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True):

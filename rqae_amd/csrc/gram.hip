@@ -1181,6 +1181,7 @@ struct Tuning {
     int cap_ab;          // pipelined schedule: CUs for projection + level chain; the reconstruction of the pass before takes the rest
     int fused;           // 1: one persistent kernel where the shape allows it, 0: always the three-kernel form
     int stagger;         // fused kernel: 1 = half first tile on odd workgroups
+    int lev2;            // level chain of one level group: 1 = lean form handing fp32 values to the reconstruction (default), 0 = first form
 };
 Tuning &tuning_mut()
 {
@@ -1198,6 +1199,8 @@ Tuning &tuning_mut()
         if (const char *e = getenv("RQAE_GRAM_PIPE")) { const long long c = atoll(e); v.pipe_chunk = c <= 0 ? 0 : ((c + 255) & ~255LL); }
         v.cap_ab = 160;
         if (const char *e = getenv("RQAE_GRAM_CAP_AB")) { const int c = atoi(e); if (c >= 8) v.cap_ab = c; }
+        v.lev2 = 1;
+        if (const char *e = getenv("RQAE_GRAM_LEV2")) v.lev2 = atoi(e) != 0;
         v.stagger = 0;
         if (const char *e = getenv("RQAE_GRAM_STAGGER")) v.stagger = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
@@ -1250,13 +1253,21 @@ GView gview(const void *packed, int d, int c, int K, int L, int shared_cb)
 
 inline long long pad64(long long n) { return (n + 63) & ~63LL; }
 
+// bytes per token of the buffer between the level chain and the reconstruction: bf16-piece operand rows (64 per k-step) or the
+// fp32 straight-through values of one level group (gram_levels2_kernel), whichever is larger
+size_t cv_row_bytes(const Geom &g, int levels)
+{
+    const size_t rows = (size_t)nks_recon(g, levels) * 64, f32 = (size_t)8 * g.CP * 4;
+    return rows > f32 ? rows : f32;
+}
+
 size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
 {
     const long long ch = n_tokens < tuning().chunk ? n_tokens : tuning().chunk;
     const long long tp = pad64(ch);
     // projections, TWO operand-row buffers (the pipelined schedule reconstructs pass i while pass i+1 fills the other one), dump
     // rows, timeline stamps (tools build)
-    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + 2 * al256((size_t)nks_recon(g, levels) * tp * 64) + 32768 + (2048 + 8 * 36 * 4) * 8;
+    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + 2 * al256(cv_row_bytes(g, levels) * tp) + 32768 + (2048 + 8 * 36 * 4) * 8;
 }
 
 bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 + (size_t)g.GL * g.GL * g.GB * 4 <= 158 * 1024; }
@@ -1393,8 +1404,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     const long long tp = pad64(chunk);
     float *P = static_cast<float *>(workspace);
     unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)g.NOG * tp * 16 * sizeof(float)));
-    unsigned *cvimg2 = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(cvimg) + al256((size_t)nks_recon(g, levels) * tp * 64));
-    float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg2) + al256((size_t)nks_recon(g, levels) * tp * 64));
+    unsigned *cvimg2 = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(cvimg) + al256(cv_row_bytes(g, levels) * tp));
+    float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg2) + al256(cv_row_bytes(g, levels) * tp));
 
     if (tuning().fused && x_dtype != RQAE_X_F32 && fused_shape_ok(g, levels)) {
         FusedParams pf;
@@ -1435,6 +1446,10 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
 #else
     // one pass = projection + level chain (phaseAB) and reconstruction (phaseC) of the tokens [t0, t0 + nt); `ncu` caps the
     // persistent grids, `cvimg` is the operand-row buffer the two halves share
+    const bool recon2_ok = tuning().recon == 2 && levels <= 8 && d % 16 == 0 &&
+        pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW <= 160 * 1024;
+    // one level group: the lean level chain hands fp32 straight-through values to the reconstruction (which splits them)
+    const bool lev2 = tuning().lev2 && levels <= 8 && g.shared_cb && g.NKC == 1 && lev2_lds_bytes(c, K) <= 160 * 1024 && (!q_out || recon2_ok);
     auto phaseAB = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark, bool strict) -> int {
         if (mark) G_TRY(hipEventRecord(ev[0], s));
         // ---- A
@@ -1510,6 +1525,26 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         }
         if (mark) G_TRY(hipEventRecord(ev[1], s));
         // ---- B
+        if (lev2) {
+            Lev2Params pl;
+            pl.P = P; pl.kconst = v.kconst; pl.gneg = v.gneg; pl.cb_img = v.cb_img; pl.cb_f32 = v.cb_f32;
+            pl.cvf = reinterpret_cast<float *>(cvimg); pl.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
+            pl.n_tokens = nt; pl.tok_pad = tp; pl.ntiles = (nt + 63) / 64;
+            pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c;
+            const size_t lds = lev2_lds_bytes(c, K);
+            long long nb = (pl.ntiles + F_NW - 1) / F_NW;
+            const long long bcap = strict ? ncu : 2LL * ncu;
+            if (nb > bcap) nb = bcap;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pl);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            const bool ceq = c == g.CP;
+            return g.CP == 4 ? (ceq ? go(gram_levels2_kernel<4, true>) : go(gram_levels2_kernel<4, false>))
+                             : (ceq ? go(gram_levels2_kernel<5, true>) : go(gram_levels2_kernel<5, false>));
+        }
         LevParams pb;
         pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
         pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
@@ -1537,12 +1572,11 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     auto phaseC = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark) -> int {
         if (mark) G_TRY(hipEventRecord(ev[2], s));
         // ---- C
-        if (q_out && tuning().recon == 2 && levels <= 8 && d % 16 == 0 &&
-            pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW <= 160 * 1024) {
+        if (q_out && recon2_ok) {
             FusedParams pf;
             memset(&pf, 0, sizeof(pf));
             pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = q_out + (size_t)t0 * d;
-            pf.cvimg = cvimg; pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c; pf.levels = levels; pf.L = L;
+            pf.cvimg = cvimg; pf.cvf = reinterpret_cast<const float *>(cvimg); pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c; pf.levels = levels; pf.L = L;
             pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET; pf.NKSC = g.NKSC; pf.stagger = 0; pf.dump = dump; pf.nks_live = nks;
             pf.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768);
             long long nb = (nt + F_TILE - 1) / F_TILE;
@@ -1554,7 +1588,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                 G_TRY(hipGetLastError());
                 return 0;
             };
-            const int rc = g.CP == 4 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 2>) : go(gram_fused_kernel<RQAE_X_BF16, 5, true, 2>);
+            const int rc = lev2 ? (g.CP == 4 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 3>) : go(gram_fused_kernel<RQAE_X_BF16, 5, true, 3>))
+                                : (g.CP == 4 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 2>) : go(gram_fused_kernel<RQAE_X_BF16, 5, true, 2>));
             if (rc) return rc;
         } else if (q_out) {
             RecParams pc;
@@ -1653,6 +1688,12 @@ int rqae_hip_gram_configure(int fused, long long pipe_chunk, int proj, int recon
     if (pipe_chunk >= 0) t.pipe_chunk = pipe_chunk == 0 ? 0 : ((pipe_chunk + 255) & ~255LL);
     if (proj >= 1 && proj <= 3) t.proj = proj;
     if (recon >= 1 && recon <= 2) t.recon = recon;
+    return 0;
+}
+
+int rqae_hip_gram_configure_levels(int lean)
+{
+    if (lean >= 0) tuning_mut().lev2 = lean != 0;
     return 0;
 }
 

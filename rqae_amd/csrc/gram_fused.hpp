@@ -45,6 +45,7 @@ struct FusedParams {
     long long tok_pad;
     int ug0;                   // MODE 1: first projection group of this launch (NG groups per launch)
     int nks_live;              // MODE 2: k-steps the levels in use fill (the rest are zero)
+    const float *cvf;          // MODE 3: fp32 straight-through values [tok_pad][8 CP]
 };
 
 constexpr int F_NW = 8;                 // waves per workgroup
@@ -53,7 +54,7 @@ constexpr int F_XCHW = 5120;            // phase B: exchange bytes per wave
 constexpr int F_ETS = 4;                // phase C: element tiles per W_out stage
 constexpr int F_XSLOT = 4096;           // phase A: one chunk of a wave's x (32 rows x 128 bytes)
 constexpr int F_TRS = 528;              // phase C: row stride of the transposition buffer (512 + 16: conflict-free writes)
-constexpr int F_TRW = 8 * F_TRS;        // phase C: transposition bytes per wave (8 token rows)
+constexpr int F_TRW = 4608;             // phase C: transposition bytes per wave (8 token rows of F_TRS; MODE 3 also passes 32 x 144 bytes through it)
 
 
 
@@ -127,7 +128,8 @@ __device__ __forceinline__ void wave_sync_lds()
 
 // CEQ: c == CP (codebook rows are CP floats apart: aligned float4 row quads)
 // MODE 0: all three phases.  MODE 1: phase A alone (projections to global memory: the first kernel of the three-kernel
-// path).  MODE 2: phase C alone (operand rows from global memory: its third kernel).  Same code, same bits.
+// path).  MODE 2 / 3: phase C alone (its third kernel; operand rows as bf16 pieces from gram_levels_kernel / as fp32 values from
+// gram_levels2_kernel).  Same code, same bits.
 template <int XT, int CP, bool CEQ, int MODE = 0>
 __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
         for (int u = 0; u < NG; ++u)
 #pragma unroll
             for (int T = 0; T < A_TT; ++T) acc[u][T] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE != 2) {
+        if constexpr (MODE < 2) {
             // Piece pc of a chunk = rows 8 pc .. 8 pc + 7 of the wave x 128 bytes; lane i = (row r = i >> 3, slot jj = i & 7)
             // lands at piece + 16 i and fetches the row's 16-byte chunk jj ^ r: LDS row r holds chunk j at slot j ^ r, and the
             // operand reads below (lane (g, n): row n, chunk 4k + g) touch 16 different bank groups per 16-lane read group.
@@ -292,6 +294,37 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
             continue;
         }
         u32x4 cvB[NKS][A_TT];
+        // cv pieces of the wave's tokens as B operands of the reconstruction: slot of (level li, component j, term) =
+        // (li CP + j) 6 + term, dword (li CP + j) 3 + {0: hi|mid, 1: hi|lo, 2: hi|mid}; lane l holds the fp32 values of token
+        // l & 31, two k-steps (32 dwords per token) per trip through the wave's LDS buffer `xb` (32 x 144 bytes)
+        auto build_cvB = [&](const float (&cvh)[GL][CP], char *xb) {
+            static_for<0, (NKS + 1) / 2>([&](auto r_c) {
+            constexpr int R = decltype(r_c)::value;
+            unsigned dwr[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int di = 32 * R + i, ci = di / 3, part = di % 3, li = ci / CP, j = ci % CP;
+                unsigned v = 0u;
+                if (ci < GL * CP) {
+                    unsigned h, m, lo;
+                    split3(cvh[li][j], h, m, lo);
+                    v = part == 1 ? pack_hi16(h, lo) : pack_hi16(h, m);
+                }
+                dwr[i] = v;
+            }
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+                *reinterpret_cast<u32x4 *>(xb + tl * 144 + 16 * v) = u32x4{dwr[4 * v], dwr[4 * v + 1], dwr[4 * v + 2], dwr[4 * v + 3]};
+            wave_sync_lds();
+#pragma unroll
+            for (int kl = 0; kl < 2; ++kl)
+                if (2 * R + kl < NKS) {
+#pragma unroll
+                    for (int T = 0; T < A_TT; ++T) cvB[2 * R + kl][T] = *reinterpret_cast<const u32x4 *>(xb + (16 * T + n) * 144 + kl * 64 + 16 * g);
+                }
+            wave_sync_lds();
+            });
+        };
         if constexpr (MODE == 0) {
         __builtin_amdgcn_s_barrier();    // LDS turns from map A into map B
         F_STAMP(2);
@@ -571,34 +604,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
         }
 
         // =========================================================================================== phase C
-        // ---- cv pieces of the wave's tokens as B operands: slot of (level li, component j, term) = (li CP + j) 6 + term,
-        // dword (li CP + j) 3 + {0: hi|mid, 1: hi|lo, 2: hi|mid}; two k-steps (32 dwords per token) per trip through LDS
-        static_for<0, (NKS + 1) / 2>([&](auto r_c) {
-            constexpr int R = decltype(r_c)::value;
-            unsigned dwr[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int di = 32 * R + i, ci = di / 3, part = di % 3, li = ci / CP, j = ci % CP;
-                unsigned v = 0u;
-                if (ci < GL * CP) {
-                    unsigned h, m, lo;
-                    split3(cvh[li][j], h, m, lo);
-                    v = part == 1 ? pack_hi16(h, lo) : pack_hi16(h, m);
-                }
-                dwr[i] = v;
-            }
-#pragma unroll
-            for (int v = 0; v < 8; ++v)
-                *reinterpret_cast<u32x4 *>(xch + tl * 144 + 16 * v) = u32x4{dwr[4 * v], dwr[4 * v + 1], dwr[4 * v + 2], dwr[4 * v + 3]};
-            wave_sync_lds();
-#pragma unroll
-            for (int kl = 0; kl < 2; ++kl)
-                if (2 * R + kl < NKS) {
-#pragma unroll
-                    for (int T = 0; T < A_TT; ++T) cvB[2 * R + kl][T] = *reinterpret_cast<const u32x4 *>(xch + (16 * T + n) * 144 + kl * 64 + 16 * g);
-                }
-            wave_sync_lds();
-        });
+        build_cvB(cvh, xch);
         F_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the code stores: the counted waits below start from zero
         __builtin_amdgcn_s_barrier();     // LDS turns from map B into map C
@@ -616,6 +622,28 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                     cvB[ks][T] = *reinterpret_cast<const u32x4 *>(p.cvimg + ((size_t)kc * p.tok_pad + tok) * 16 + 4 * g);
                     if (ks >= p.nks_live) cvB[ks][T] = u32x4{0u, 0u, 0u, 0u};
                 }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (MODE == 3) {
+            // fp32 straight-through values written by gram_levels2_kernel, [token][GL * CP] (zeros past the depth in use): the
+            // split into bf16 pieces happens here, on the memory-bound side
+            float cvf[GL][CP];
+            {
+                long long tok = tw0 + tl;
+                tok = tok < tile_end ? tok : tile_end - 1;
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cvf + (size_t)tok * (GL * CP));
+                float flat[GL * CP];
+#pragma unroll
+                for (int v = 0; v < GL * CP / 4; ++v) {
+                    const f32x4 w = src[v];
+                    flat[4 * v] = w[0]; flat[4 * v + 1] = w[1]; flat[4 * v + 2] = w[2]; flat[4 * v + 3] = w[3];
+                }
+#pragma unroll
+                for (int li = 0; li < GL; ++li)
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) cvf[li][j] = flat[li * CP + j];
+            }
+            build_cvB(cvf, trb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         {
@@ -731,5 +759,305 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
         F_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();     // LDS turns back into map A
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ level chain, lean form
+// The level chain of the three-kernel path for one level group (levels <= 8): the arithmetic of gram_levels_kernel / phase B
+// above (same scores, same rescoring, same Gram updates: same codes), with what made that kernel issue-bound taken out of it:
+//   * the straight-through values leave as fp32 ([token][8 CP], 160 bytes per token at c = 5 instead of 512 bytes of bf16
+//     pieces): the split into pieces moves to the reconstruction kernel (MODE 3), which waits on HBM anyway;
+//   * c == CP and the shared codebook are template facts (aligned float4 row quads, no per-component bounds);
+//   * Gram blocks come from LDS (broadcast reads, next block read while this one is multiplied);
+//   * whole row tiles are scanned unmasked (rows past K repeat row 0 in the image).
+// One wave = 64 tokens, one token per lane in c-space; 8 waves per workgroup share the LDS tables; persistent over tiles.
+struct Lev2Params {
+    const float *P;            // [NOG][tok_pad][16]
+    const float *kconst;       // [NOG * 16]
+    const float *gneg;         // [L][L][GB]
+    const uint16_t *cb_img;    // [KTP][512]
+    const float *cb_f32;       // [K + 64][c], whole KiB
+    float *cvf;                // [tok_pad][8 CP]
+    long long *idx;            // [n_tokens][levels]
+    long long n_tokens, tok_pad, ntiles;
+    int levels, L, K, KTP, c;
+};
+
+__host__ __device__ inline size_t lev2_lds_bytes(int c, int K)
+{
+    const int CP = cp_of(c);
+    const size_t KTP = (((size_t)(K + 15) / 16 + 3) / 4) * 4, gb = (CP * CP + 3) & ~3;
+    return KTP * 1024 + pad1k(((size_t)K + 64) * c * 4) + F_NW * 4096 + 64 * gb * 4;
+}
+
+template <int CP, bool CEQ>
+__global__ __launch_bounds__(F_NW * 64) void gram_levels2_kernel(Lev2Params p)
+{
+    constexpr int GL = 8, GP = ((GL * CP + 15) / 16) * 16, NG = GP / 16, GB = (CP * CP + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
+    const int c = CEQ ? CP : p.c;
+    const int levels = p.levels;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    char *cbl = smem;
+    const unsigned off_cbf = (unsigned)p.KTP * 1024u;
+    const unsigned cbf_bytes = (unsigned)pad1k(((size_t)p.K + 64) * c * 4);
+    const float *cbf = reinterpret_cast<const float *>(smem + off_cbf);
+    char *xch = smem + off_cbf + cbf_bytes + wave * 4096;
+    float *sgram = reinterpret_cast<float *>(smem + off_cbf + cbf_bytes + F_NW * 4096);
+    {   // tables: codebook image + fp32 rows by LDS-DMA, Gram blocks of the group by the threads
+        const int npi = p.KTP + (int)(cbf_bytes >> 10);
+        for (int q = wave; q < npi; q += F_NW) {
+            const void *src = q < p.KTP ? static_cast<const void *>(p.cb_img + (size_t)q * 512)
+                                        : static_cast<const void *>(reinterpret_cast<const char *>(p.cb_f32) + (size_t)(q - p.KTP) * 1024);
+            dma_piece(uniform_ptr(src), lds0 + q * 1024, (unsigned)lane * 16u);
+        }
+        for (int i = tid; i < GL * GL * GB; i += F_NW * 64) {
+            const int blk = i / GB, li = blk / GL, li2 = blk - li * GL;
+            sgram[i] = (li < p.L && li2 < p.L) ? p.gneg[((size_t)li * p.L + li2) * GB + (i - blk * GB)] : 0.0f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const int wq = (lane >> 2) & 3;
+    const int ngrp = p.KTP / 4;
+    for (long long tile = (long long)blockIdx.x * F_NW + wave; tile < p.ntiles; tile += (long long)gridDim.x * F_NW) {
+        const long long t = tile * 64 + lane;          // < tok_pad
+        float Q[GL][CP];
+        {
+            float buf[NG * 16];
+#pragma unroll
+            for (int u = 0; u < NG; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(p.P + (((size_t)u * p.tok_pad + t) * 16 + 4 * v));
+                    const f32x4 kc = *reinterpret_cast<const f32x4 *>(p.kconst + 16 * u + 4 * v);
+                    buf[16 * u + 4 * v + 0] = w[0] + kc[0];
+                    buf[16 * u + 4 * v + 1] = w[1] + kc[1];
+                    buf[16 * u + 4 * v + 2] = w[2] + kc[2];
+                    buf[16 * u + 4 * v + 3] = w[3] + kc[3];
+                }
+#pragma unroll
+            for (int li = 0; li < GL; ++li)
+#pragma unroll
+                for (int j = 0; j < CP; ++j) Q[li][j] = buf[li * CP + j];
+        }
+        float cvh[GL][CP];
+        int codes[GL];
+        static_for<0, GL>([&](auto li_c) {
+            constexpr int li = decltype(li_c)::value;
+            if (li < levels) {
+                float q[CP];
+#pragma unroll
+                for (int j = 0; j < CP; ++j) q[j] = Q[li][j];
+                float n2 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
+                const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
+                {   // B operand rows of the wave's 64 tokens: 32 slots = 64 bytes per token
+                    unsigned dw[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dw[i] = 0u;
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) {
+                        unsigned h, m, lo;
+                        split3(q[j], h, m, lo);
+                        dw[3 * j] = pack_hi16(h, m);
+                        dw[3 * j + 1] = pack_hi16(h, lo);
+                        dw[3 * j + 2] = dw[3 * j];
+                    }
+#pragma unroll
+                    for (int pc = 0; pc < 4; ++pc) {
+                        const int pos = (pc + 2 * wq) & 3;   // bank-conflict-free placement of the four 16-byte pieces
+                        *reinterpret_cast<u32x4 *>(xch + lane * 64 + pos * 16) = u32x4{dw[4 * pc], dw[4 * pc + 1], dw[4 * pc + 2], dw[4 * pc + 3]};
+                    }
+                }
+                wave_sync_lds();
+                u32x4 B[4];
+#pragma unroll
+                for (int T = 0; T < 4; ++T) {
+                    const int pos = (g + 2 * ((n >> 2) & 3)) & 3;
+                    B[T] = *reinterpret_cast<const u32x4 *>(xch + (16 * T + n) * 64 + pos * 16);
+                }
+                // ---- scan: running maximum per (lane, token tile) over groups of 4 row tiles (16 rows per lane)
+                float best[4];
+                int bgrp[4];
+#pragma unroll
+                for (int T = 0; T < 4; ++T) { best[T] = -INFINITY; bgrp[T] = 0; }
+                u32x4 an[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u32x4 *>(cbl + i * 1024 + lane * 16);
+                for (int grp = 0; grp < ngrp; ++grp) {
+                    float mx[4];
+                    u32x4 a[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = an[i];
+                    const int gn = grp + 1 < ngrp ? grp + 1 : grp;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u32x4 *>(cbl + (gn * 4 + i) * 1024 + lane * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // four independent MFMAs back to back (one per token tile), then their maxima (v_maximum3_f32: a NaN score
+                        // poisons the maximum, which then never beats `best`; the level takes index 0 through okq)
+                        f32x4 s[4];
+#pragma unroll
+                        for (int T = 0; T < 4; ++T) s[T] = mfma16(a[i], B[T], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                        for (int T = 0; T < 4; ++T) {
+                            const float m012 = __builtin_elementwise_maximum(__builtin_elementwise_maximum(s[T][0], s[T][1]), s[T][2]);
+                            if (i == 0) mx[T] = __builtin_elementwise_maximum(m012, s[T][3]);
+                            else mx[T] = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m012, s[T][3]), mx[T]);
+                        }
+                    }
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) {
+                        const bool up = mx[T] > best[T];
+                        best[T] = up ? mx[T] : best[T];
+                        bgrp[T] = up ? grp : bgrp[T];
+                    }
+                }
+                // ---- the four lanes (g) of a token hand their (maximum, group) to the token's own lane
+                wave_sync_lds();
+#pragma unroll
+                for (int T = 0; T < 4; ++T) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                    *reinterpret_cast<u32x2 *>(xch + ((16 * T + n) * 4 + g) * 8) = u32x2{u32_of(best[T]), (unsigned)bgrp[T]};
+                }
+                wave_sync_lds();
+                const u32x4 h0 = *reinterpret_cast<const u32x4 *>(xch + lane * 32);
+                const u32x4 h1 = *reinterpret_cast<const u32x4 *>(xch + lane * 32 + 16);
+                wave_sync_lds();
+                float bv = f32_of(h0[0]);
+                int bgr = (int)h0[1], bg = 0;
+                bool amb = false;
+                {
+                    const float vv[3] = {f32_of(h0[2]), f32_of(h1[0]), f32_of(h1[2])};
+                    const int gg[3] = {(int)h0[3], (int)h1[1], (int)h1[3]};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const bool gt = vv[k] > bv, eq = vv[k] == bv;
+                        const bool take = gt || (eq && gg[k] < bgr);
+                        amb = take ? false : (amb || (eq && gg[k] == bgr));
+                        bv = take ? vv[k] : bv;
+                        bg = take ? k + 1 : bg;
+                        bgr = take ? gg[k] : bgr;
+                    }
+                }
+                if (!okq) { bgr = 0; bg = 0; amb = false; }
+                // ---- the 16 rows behind that maximum rescored in fp32 (the reference's k-ordered fma chain), first maximum in row
+                // order wins: all scores first, then a pairwise tournament in row order (the left entry keeps ties)
+                int brow;
+                {
+                    float sc[16];
+                    int rw[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r0 = 16 * (4 * bgr + i) + 4 * bg;
+                        float f[4 * CP];
+                        if (CEQ) {
+                            const f32x4 *qp = reinterpret_cast<const f32x4 *>(cbf + (size_t)r0 * CP);
+#pragma unroll
+                            for (int w = 0; w < CP; ++w) {
+                                const f32x4 v = qp[w];
+                                f[4 * w] = v[0]; f[4 * w + 1] = v[1]; f[4 * w + 2] = v[2]; f[4 * w + 3] = v[3];
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int j = 0; j < CP; ++j) f[r * CP + j] = j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float acc_s = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(f[r * CP + j], q[j], acc_s);
+                            sc[4 * i + r] = (r0 + r < p.K) ? acc_s : -INFINITY;
+                            rw[4 * i + r] = r0 + r;
+                        }
+                    }
+#pragma unroll
+                    for (int st2 = 1; st2 < 16; st2 *= 2)
+#pragma unroll
+                        for (int k = 0; k < 16; k += 2 * st2) {
+                            const bool right = sc[k + st2] > sc[k];
+                            sc[k] = right ? sc[k + st2] : sc[k];
+                            rw[k] = right ? rw[k + st2] : rw[k];
+                        }
+                    brow = rw[0];
+                }
+                // equal maxima in one 64-row block on several lanes (duplicate rows): rescan the block in row order; rare, so the
+                // wave branches around it
+                if (__builtin_amdgcn_ballot_w64(amb) != 0) {
+                    if (amb) {
+                        float bsc = -INFINITY;
+                        brow = 64 * bgr;
+#pragma unroll 1
+                        for (int r0 = 64 * bgr; r0 < 64 * bgr + 64; r0 += 4) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float acc_s = 0.0f;
+#pragma unroll
+                                for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f, q[j], acc_s);
+                                const bool up = (acc_s > bsc) && (r0 + r < p.K);
+                                bsc = up ? acc_s : bsc;
+                                brow = up ? r0 + r : brow;
+                            }
+                        }
+                    }
+                }
+                if (!okq) brow = 0;
+                codes[li] = brow;
+                // ---- straight-through value (rqae/model.py:218-220)
+#pragma unroll
+                for (int j = 0; j < CP; ++j) {
+                    const float cv = j < c ? cbf[(size_t)brow * c + j] : 0.0f;
+                    const float df = cv - q[j];
+                    cvh[li][j] = q[j] + df;
+                }
+                // ---- later levels see the level just applied (every block of the group is staged: zeros past the depth in use)
+                if constexpr (li + 1 < GL) {
+                    float gbr[2][GB];
+                    auto rd = [&](int li2, float (&dst)[GB]) {
+                        const float *gb = sgram + (li * GL + li2) * GB;        // broadcast reads
+#pragma unroll
+                        for (int w = 0; w < GB / 4; ++w) {
+                            const f32x4 v = *reinterpret_cast<const f32x4 *>(gb + 4 * w);
+                            dst[4 * w] = v[0]; dst[4 * w + 1] = v[1]; dst[4 * w + 2] = v[2]; dst[4 * w + 3] = v[3];
+                        }
+                    };
+                    rd(li + 1, gbr[0]);
+#pragma unroll
+                    for (int li2 = li + 1; li2 < GL; ++li2) {
+                        const int cur = (li2 - li - 1) & 1;
+                        if (li2 + 1 < GL) rd(li2 + 1, gbr[cur ^ 1]);
+#pragma unroll
+                        for (int j = 0; j < CP; ++j)
+#pragma unroll
+                            for (int i = 0; i < CP; ++i) Q[li2][j] = __builtin_fmaf(gbr[cur][j * CP + i], cvh[li][i], Q[li2][j]);
+                    }
+                }
+            } else {
+                codes[li] = 0;
+#pragma unroll
+                for (int j = 0; j < CP; ++j) cvh[li][j] = 0.0f;
+            }
+        });
+        // ---- codes and fp32 straight-through values of the tile
+        if (t < p.n_tokens) {
+#pragma unroll
+            for (int li = 0; li < GL; ++li)
+                if (li < levels) p.idx[t * levels + li] = (long long)codes[li];
+        }
+        {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(p.cvf + (size_t)t * (GL * CP));
+            float flat[GL * CP];
+#pragma unroll
+            for (int li = 0; li < GL; ++li)
+#pragma unroll
+                for (int j = 0; j < CP; ++j) flat[li * CP + j] = cvh[li][j];
+#pragma unroll
+            for (int v = 0; v < GL * CP / 4; ++v) dst[v] = f32x4{flat[4 * v], flat[4 * v + 1], flat[4 * v + 2], flat[4 * v + 3]};
+        }
     }
 }

@@ -215,6 +215,40 @@ int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, 
                                 int x_dtype, int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,
                                 void *stream, float *phase_ms);
 
+/* ---- Similarity search over a resident dataset of codes ------------------------------
+ * Replaces the arithmetic of demo/server/server.py: get_intensities (:41-68) and IntensityEngine.find_examples
+ * (:160-325).  The caller (rqae_amd/search.py mirrors find_examples) walks the layer ranges; per range [l0, l1):
+ *   rqae_hip_search_query_table  table_out[l - l0][k][q] fp16 = sims16[l][ query_codes[q * query_stride + l] ][k]
+ *                                (server.py:186-200 with the row's two axes swapped: one dataset code then needs ONE
+ *                                contiguous row).  sims16 [L][K][K] fp16 is the table the server keeps after
+ *                                `sims *= layer_norms` (:101-112; rqae_hip_subfeature_sims writes it).  Rows padded to
+ *                                128 query positions and K to a multiple of 16 (zeros);
+ *                                rqae_hip_search_table_bytes(K, l1 - l0) bytes.  Query codes must be in [0, K).
+ *   rqae_hip_search_accumulate   acc[t][q] (fp16, [n_tokens][128], n_tokens = sequences x positions) takes the range's
+ *                                intensities: per (t, q) the fp32 sum over ascending levels of
+ *                                table[l][codes[t][l]][q], rounded to fp16 per chunk of <= 64 levels, chunks added
+ *                                in fp16 (server.py:214-252), and the range added to acc in fp16 (:257-260; first != 0
+ *                                stores instead, as the reference's first range does).  codes [n_tokens][L] int32 or
+ *                                uint16 (RQAE_IDX_*), device-resident; a code >= K reads zeros.
+ *   rqae_hip_search_rank         max_out[q][r] fp16 / order_out[q][r] int32: per query position the sequences by
+ *                                descending max over positions of acc (server.py:263-266); equal maxima in ascending
+ *                                sequence order (torch.argsort there promises none).  Sequence n = tokens
+ *                                [n S, (n + 1) S).  workspace: rqae_hip_search_rank_workspace_bytes(n_seqs, Q).
+ *   rqae_hip_search_gather       out[q][e][s] fp16 = acc[examples[q * E + e]][s][q]  (server.py:293-311)
+ * Supported: Q <= 128, K <= 1280 (rqae_hip_search_supported).  All pointers are device pointers; acc and table_out
+ * 16-byte aligned. */
+int rqae_hip_search_supported(int K, int Q);
+size_t rqae_hip_search_table_bytes(int K, int n_levels);
+int rqae_hip_search_query_table(const void *sims16, int L, int K, const int32_t *query_codes, int Q, int64_t query_stride,
+                                int l0, int l1, void *table_out, void *stream);
+int rqae_hip_search_accumulate(const void *codes, int code_dtype, int64_t n_tokens, int L, const void *table, int K, int Q,
+                               int l0, int l1, void *acc, int first, void *stream);
+size_t rqae_hip_search_rank_workspace_bytes(int64_t n_seqs, int Q);
+int rqae_hip_search_rank(const void *acc, int64_t n_seqs, int S, int Q, void *max_out, int32_t *order_out, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int rqae_hip_search_gather(const void *acc, int64_t n_seqs, int S, int Q, const int32_t *examples, int E, void *out,
+                           void *stream);
+
 /* Human-readable name of the encode kernel variant chosen for a shape. */
 int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);
 

@@ -47,6 +47,13 @@ SYMBOLS = (
     "rqae_hip_encode_gram_phases",
     "rqae_hip_gram_configure",
     "rqae_hip_gram_configure_levels",
+    "rqae_hip_search_supported",
+    "rqae_hip_search_table_bytes",
+    "rqae_hip_search_query_table",
+    "rqae_hip_search_accumulate",
+    "rqae_hip_search_rank_workspace_bytes",
+    "rqae_hip_search_rank",
+    "rqae_hip_search_gather",
 )
 
 _lib = None
@@ -120,6 +127,20 @@ def lib():
     L.rqae_hip_gram_configure.restype = i
     L.rqae_hip_gram_configure_levels.argtypes = [i]
     L.rqae_hip_gram_configure_levels.restype = i
+    L.rqae_hip_search_supported.argtypes = [i, i]
+    L.rqae_hip_search_supported.restype = i
+    L.rqae_hip_search_table_bytes.argtypes = [i, i]
+    L.rqae_hip_search_table_bytes.restype = sz
+    L.rqae_hip_search_query_table.argtypes = [vp, i, i, vp, i, i64, i, i, vp, vp]
+    L.rqae_hip_search_query_table.restype = i
+    L.rqae_hip_search_accumulate.argtypes = [vp, i, i64, i, vp, i, i, i, i, vp, i, vp]
+    L.rqae_hip_search_accumulate.restype = i
+    L.rqae_hip_search_rank_workspace_bytes.argtypes = [i64, i]
+    L.rqae_hip_search_rank_workspace_bytes.restype = sz
+    L.rqae_hip_search_rank.argtypes = [vp, i64, i, i, vp, vp, vp, sz, vp]
+    L.rqae_hip_search_rank.restype = i
+    L.rqae_hip_search_gather.argtypes = [vp, i64, i, i, vp, i, vp, vp]
+    L.rqae_hip_search_gather.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"librqae_hip.so ABI {L.rqae_hip_abi_version()} != expected {ABI_VERSION}; rebuild")
@@ -520,3 +541,76 @@ def kernel_info(d: int, c: int, K: int, L: int) -> str:
     rc = lib().rqae_hip_kernel_info(d, c, K, L, buf, 256)
     _check(rc, "rqae_hip_kernel_info")
     return buf.value.decode()
+
+
+# ---- similarity search over resident codes (csrc/search.hip; include/rqae_hip.h "Similarity search") ---------------
+
+def search_supported(K: int, Q: int) -> bool:
+    return bool(lib().rqae_hip_search_supported(K, Q))
+
+
+def search_query_table(sims16: torch.Tensor, query_codes: torch.Tensor, l0: int, l1: int, out: torch.Tensor | None = None):
+    """sims16 [L,K,K] fp16, query_codes [Q, >= l1] int32 -> the range's table [l1-l0, KP, 128] fp16 (as a flat byte tensor)."""
+    _require_cuda(sims16, "sims")
+    _require_cuda(query_codes, "query codes")
+    L_, K, K2 = sims16.shape
+    if sims16.dtype != torch.float16 or not sims16.is_contiguous() or K != K2:
+        raise RuntimeError("search_query_table: sims must be contiguous float16 [L, K, K]")
+    if query_codes.dtype != torch.int32 or query_codes.dim() != 2 or query_codes.stride(1) != 1:
+        raise RuntimeError("search_query_table: query codes must be int32 [Q, levels] with unit level stride")
+    Q = query_codes.shape[0]
+    need = int(lib().rqae_hip_search_table_bytes(K, l1 - l0))
+    if out is None or out.numel() < need:
+        out = torch.empty(max(need, 16), dtype=torch.uint8, device=sims16.device)
+    with torch.cuda.device(sims16.device):
+        rc = lib().rqae_hip_search_query_table(sims16.data_ptr(), L_, K, query_codes.data_ptr(), Q, query_codes.stride(0), l0, l1,
+                                               out.data_ptr(), _stream(sims16.device))
+    _check(rc, "rqae_hip_search_query_table")
+    return out
+
+
+def search_accumulate(codes: torch.Tensor, table: torch.Tensor, K: int, Q: int, l0: int, l1: int, acc: torch.Tensor, first: bool):
+    """codes [N,S,L] int32/uint16 (resident), table from search_query_table, acc [N,S,128] fp16 updated in place."""
+    _require_cuda(codes, "codes")
+    if codes.dtype not in (torch.int32, torch.uint16) or not codes.is_contiguous() or codes.dim() != 3:
+        raise RuntimeError("search_accumulate: codes must be contiguous int32 or uint16 [N, S, L]")
+    N, S, L_ = codes.shape
+    if acc.dtype != torch.float16 or tuple(acc.shape) != (N, S, 128) or not acc.is_contiguous() or acc.device != codes.device:
+        raise RuntimeError("search_accumulate: acc must be contiguous float16 [N, S, 128] on the codes' device")
+    with torch.cuda.device(codes.device):
+        rc = lib().rqae_hip_search_accumulate(codes.data_ptr(), _IDX_DTYPES[codes.dtype], N * S, L_, table.data_ptr(), K, Q, l0, l1,
+                                              acc.data_ptr(), int(bool(first)), _stream(codes.device))
+    _check(rc, "rqae_hip_search_accumulate")
+
+
+def search_rank(acc: torch.Tensor, Q: int, workspace: torch.Tensor | None = None):
+    """acc [N,S,128] fp16 -> (max values [Q,N] fp16 descending, sequence numbers [Q,N] int32, workspace)."""
+    _require_cuda(acc, "acc")
+    N, S, _ = acc.shape
+    need = int(lib().rqae_hip_search_rank_workspace_bytes(N, Q))
+    if need == 0:
+        raise RuntimeError(f"search_rank: unsupported shape N={N} Q={Q}")
+    if workspace is None or workspace.numel() < need or workspace.device != acc.device:
+        workspace = torch.empty(need, dtype=torch.uint8, device=acc.device)
+    mx = torch.empty((Q, N), dtype=torch.float16, device=acc.device)
+    order = torch.empty((Q, N), dtype=torch.int32, device=acc.device)
+    with torch.cuda.device(acc.device):
+        rc = lib().rqae_hip_search_rank(acc.data_ptr(), N, S, Q, mx.data_ptr(), order.data_ptr(), workspace.data_ptr(), workspace.numel(),
+                                        _stream(acc.device))
+    _check(rc, "rqae_hip_search_rank")
+    return mx, order, workspace
+
+
+def search_gather(acc: torch.Tensor, Q: int, examples: torch.Tensor) -> torch.Tensor:
+    """acc [N,S,128] fp16, examples [Q,E] int32 -> [Q,E,S] fp16."""
+    _require_cuda(acc, "acc")
+    N, S, _ = acc.shape
+    if examples.dtype != torch.int32 or examples.dim() != 2 or examples.shape[0] != Q or not examples.is_contiguous():
+        raise RuntimeError("search_gather: examples must be contiguous int32 [Q, E]")
+    E = examples.shape[1]
+    out = torch.empty((Q, E, S), dtype=torch.float16, device=acc.device)
+    if E:
+        with torch.cuda.device(acc.device):
+            rc = lib().rqae_hip_search_gather(acc.data_ptr(), N, S, Q, examples.data_ptr(), E, out.data_ptr(), _stream(acc.device))
+        _check(rc, "rqae_hip_search_gather")
+    return out

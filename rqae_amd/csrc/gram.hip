@@ -1147,6 +1147,16 @@ __global__ __launch_bounds__(NW * 64) void gram_reconstruct_kernel(RecParams p)
     u32x4 BX[TT][NKS], BY[TT][NKS];
     long long pi = (long long)lq * NW + wave;
     if (xcd + 8 * pi >= p.npairs) return;
+    if constexpr (TT * NKS > 16) {
+        // two register sets of cv pieces no longer fit (hipcc would spill asm-loaded registers before their wait): one set,
+        // loaded and waited for per group
+        for (; xcd + 8 * pi < p.npairs; pi += stride) {
+            loadB(BX, xcd + 8 * pi);
+            waitB(BX, std::integral_constant<int, 0>{});
+            group(BX, BX, xcd + 8 * pi);
+        }
+        return;
+    }
     loadB(BX, xcd + 8 * pi);
     waitB(BX, std::integral_constant<int, 0>{});
     for (;;) {
@@ -1168,6 +1178,7 @@ __global__ __launch_bounds__(NW * 64) void gram_reconstruct_kernel(RecParams p)
 }
 
 #include "gram_fused.hpp"
+#include "gram_stream.hpp"
 
 constexpr int B_NW = 8;
 
@@ -1272,6 +1283,9 @@ size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
 
 bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 + (size_t)g.GL * g.GL * g.GB * 4 <= 158 * 1024; }
 
+// a codebook too large for LDS streams through it (gram_stream.hpp): one shared codebook, one k-step per cosine contraction
+bool levels_stream_ok(const Geom &g) { return g.shared_cb && g.NKC == 1 && g.CP <= 5; }
+
 // the one-kernel form: one level group, whole chunks of 2 k-steps, everything resident fits the CU's 160 KiB of LDS
 bool fused_shape_ok(const Geom &g, int levels)
 {
@@ -1324,7 +1338,7 @@ int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared)
 {
     if (!gram_shape_ok(d, c, K, L)) return 0;
     const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
-    return levels_resident_ok(g) ? 1 : 0;
+    return (levels_resident_ok(g) || levels_stream_ok(g)) ? 1 : 0;
 }
 
 size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared)
@@ -1550,7 +1564,27 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
         pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
         pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
-        {
+        if (!levels_resident_ok(g)) {
+            // persistent: a workgroup's waves walk the ring together.  8 waves per workgroup halve the L2 -> LDS refill per token;
+            // 4 when 8 would leave CUs without a workgroup
+            const int nw = (pb.ntiles + SL_NW - 1) / SL_NW >= ncu ? SL_NW : 4;
+            const size_t lds = stream_lds_bytes(nw);
+            long long nb = (pb.ntiles + nw - 1) / nw;
+            if (nb > ncu) nb = ncu;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nw * 64), lds, s, pb);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            const bool multi = levels > g.GL;
+            int rc;
+#define SLK(CPV, MV) (nw == SL_NW ? go(gram_levels_stream_kernel<CPV, MV, SL_NW>) : go(gram_levels_stream_kernel<CPV, MV, 4>))
+            if (g.CP == 4) rc = multi ? SLK(4, true) : SLK(4, false);
+            else rc = multi ? SLK(5, true) : SLK(5, false);
+#undef SLK
+            if (rc) return rc;
+        } else {
             const size_t lds = (size_t)g.KTP * g.NKC * 1024 + ((((size_t)K + 64) * c * 4 + 15) & ~(size_t)15) + (size_t)B_NW * g.NKC * 4096 +
                                (size_t)g.GL * g.GL * g.GB * 4;
             long long nb = (pb.ntiles + B_NW - 1) / B_NW;

@@ -193,6 +193,43 @@ def test_gram_full_size_c2_and_north_star_size():
         torch.cuda.empty_cache()
 
 
+def test_gram_c5_streamed_codebook_depth_32():
+    """BASELINE configs[4] as stated: d 2304, K 4096, depth 32.  The codebook image (256 KB) streams through LDS
+    (csrc/gram_stream.hpp), four level groups correct one another through the workspace.  Oracle on 2000 tokens (fp32 and bf16
+    inputs, and a shallower call), then 65 536 bf16 tokens against the exact arm with every differing token adjudicated."""
+    cfg = synth.CONFIGS["C5"]
+    assert cfg["codebook_size"] ** cfg["codebook_dim"] == 4096 and cfg["num_quantizers"] == 32
+    w = synth.weights(555, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    assert m._use_gram(2000, 32)
+    x = synth.activations(31, 2000, cfg["dim"])
+    for dt in (torch.float32, torch.bfloat16):
+        q, idx, xs = run(m, x, dt)
+        assert idx.shape == (2000, 32) and idx.max() < 4096
+        check_tier2(xs, w, q, idx)
+    q, idx, xs = run(m, x[:300], torch.float32, max_layers=19)
+    check_tier2(xs, w, q, idx, levels=19)
+    # a batch that fills the chip
+    me_ = make_model(cfg, w, "exact")
+    n = 65536
+    g = torch.Generator(device=DEV); g.manual_seed(8)
+    z = torch.randn(n, cfg["dim"], device=DEV, generator=g)
+    xb = (z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16)
+    with torch.inference_mode():
+        q, idx = m(xb.view(1, n, -1))
+        qe, ie = me_(xb.view(1, n, -1))
+    bad = (idx[0] != ie[0]).any(dim=1)
+    rows = torch.nonzero(bad).flatten().cpu().numpy()
+    assert len(rows) <= n // 2000, f"{len(rows)} of {n} tokens differ from the exact arm"
+    same = ~bad
+    scale = qe[0][same].abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert float(((q[0][same] - qe[0][same]).abs() / scale).max()) < RTOL
+    sel = np.unique(np.concatenate([rows, np.arange(0, n, 257)]))
+    listed = check_tier2(xb[sel].float().cpu().numpy(), w, q[0][sel].cpu().numpy(), idx[0][sel].cpu().numpy())
+    assert listed == len(rows)
+    print(f"gram arm, C5 depth 32, {n} tokens: {len(rows)} low-margin tokens differ from the exact arm, all adjudicated")
+
+
 def test_gram_deep_shape_and_half_inputs():
     """The pretrained shape's (c 4, K 625: duplicate rows, a zero row, a ragged last row block) first 16 levels -- two
     level groups, so later groups' projections are corrected through the workspace -- in all three input types."""

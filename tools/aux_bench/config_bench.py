@@ -1,0 +1,55 @@
+"""Forward of a named BASELINE config on both arms, with the matrix-core arm's per-kernel times.
+
+    python tools/aux_bench/config_bench.py C5 65536 [--levels N] [--dtype bf16|f32]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from rqae_amd import RQAE, _native, synth  # noqa: E402
+
+
+def timed(fn, reps=5):
+    with torch.inference_mode():
+        fn(); fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("config")
+ap.add_argument("tokens", type=int)
+ap.add_argument("--levels", type=int, default=0)
+ap.add_argument("--dtype", default="bf16")
+a = ap.parse_args()
+cfg = dict(synth.CONFIGS[a.config])
+if a.levels:
+    cfg["num_quantizers"] = a.levels
+w = synth.weights(1, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+out = {"config": a.config, **cfg, "tokens": a.tokens, "dtype": a.dtype}
+x = torch.randn(1, a.tokens, cfg["dim"], device="cuda")
+x = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+for arm in ("exact", "gram"):
+    m = RQAE(**cfg, arm=arm).eval()
+    m.load_state_dict(synth.state_dict_from_weights(w))
+    m = m.to("cuda")
+    K = m.codebook.shape[1]
+    if arm == "gram" and not _native.gram_supported(m._dims(), True):
+        out["gram"] = "not served"
+        continue
+    ms = timed(lambda: m(x))
+    out[arm] = {"ms": round(ms, 3), "Mtok_per_s": round(a.tokens / ms / 1e3, 2)}
+    if arm == "exact":
+        out[arm]["kernel"] = _native.kernel_info(cfg["dim"], cfg["codebook_dim"], K, cfg["num_quantizers"])
+    else:
+        ph = _native.encode_gram_phases(m.gram_packed_weights(), m._dims(), x.view(-1, cfg["dim"]), cfg["num_quantizers"])
+        out[arm]["kernel_ms"] = {"project": round(ph[0], 3), "levels": round(ph[1], 3), "reconstruct": round(ph[2], 3)}
+print(json.dumps(out))

@@ -41,7 +41,7 @@ PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # component in the cosine and reconstruction contractions)
 GRAM_MFMA_FLOPS_PER_TOKEN = 2 * D * 48 * 3 + L * 2 * K * 32 + 2 * D * 256
 
-KERNEL_SOURCES = ["gram.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
+KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
 
 
 def sources_hash():

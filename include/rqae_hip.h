@@ -198,6 +198,13 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
 size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels);
 int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
                          int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream);
+/* RQAE.decode (rqae/model.py:250-252) on the matrix-core arm, every level of indices [n_tokens][levels] selected: the decode sum
+ * as rqae_hip_encode_gram's reconstruction kernel computes it (bf16-piece products, fp32 accumulation: within 1e-6 relative of
+ * rqae_hip_decode, not its bits), codebook rows gathered by the codes in the kernel.  HBM-write-bound: 9 216 + 8 levels bytes per
+ * token at d = 2304.  Served for levels <= 8 (one level group); codes int64 / int32 / uint16, PRECONDITION 0 <= code < K. */
+int rqae_hip_decode_gram_supported(int d, int c, int K, int L, int codebook_shared, int levels);
+int rqae_hip_decode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *indices, int idx_dtype,
+                         int64_t n_tokens, int levels, float *out, void *stream);
 /* Which kernels rqae_hip_encode_gram launches (defaults in parentheses; -1 leaves a setting as it is; the environment
  * variables RQAE_GRAM_FUSED / _PIPE / _PROJ / _RECON set the same at load).  Every combination computes the same function
  * under the same parity policy; they differ in speed.  Process-wide, not thread-safe against

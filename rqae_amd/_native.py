@@ -47,6 +47,8 @@ SYMBOLS = (
     "rqae_hip_encode_gram_phases",
     "rqae_hip_gram_configure",
     "rqae_hip_gram_configure_levels",
+    "rqae_hip_decode_gram_supported",
+    "rqae_hip_decode_gram",
     "rqae_hip_search_supported",
     "rqae_hip_search_table_bytes",
     "rqae_hip_search_query_table",
@@ -127,6 +129,10 @@ def lib():
     L.rqae_hip_gram_configure.restype = i
     L.rqae_hip_gram_configure_levels.argtypes = [i]
     L.rqae_hip_gram_configure_levels.restype = i
+    L.rqae_hip_decode_gram_supported.argtypes = [i, i, i, i, i, i]
+    L.rqae_hip_decode_gram_supported.restype = i
+    L.rqae_hip_decode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp]
+    L.rqae_hip_decode_gram.restype = i
     L.rqae_hip_search_supported.argtypes = [i, i]
     L.rqae_hip_search_supported.restype = i
     L.rqae_hip_search_table_bytes.argtypes = [i, i]
@@ -269,6 +275,28 @@ def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels:
                                         idx.data_ptr(), workspace.data_ptr(), _stream(x2d.device))
     _check(rc, "rqae_hip_encode_gram")
     return q, idx
+
+
+def decode_gram_supported(dims, codebook_shared: bool, levels: int) -> bool:
+    d, c, K, L_ = dims
+    return bool(lib().rqae_hip_decode_gram_supported(d, c, K, L_, int(bool(codebook_shared)), levels))
+
+
+def decode_gram(gpacked, dims, codebook_shared: bool, idx2d: torch.Tensor) -> torch.Tensor:
+    """idx2d [N, levels] {i64,i32,u16} -> out [N,d] f32: every level selected, on the matrix-core arm (include/rqae_hip.h)."""
+    d, c, K, L_ = dims
+    _require_cuda(idx2d, "indices")
+    if idx2d.dtype not in _IDX_DTYPES or idx2d.dim() != 2 or not idx2d.is_contiguous():
+        raise RuntimeError("decode_gram: indices must be contiguous int64 / int32 / uint16 [N, levels]")
+    n, levels = idx2d.shape
+    check_codes(idx2d, K, "decode", always=True)
+    out = torch.empty((n, d), dtype=torch.float32, device=idx2d.device)
+    if n:
+        with torch.cuda.device(idx2d.device):
+            rc = lib().rqae_hip_decode_gram(gpacked.data_ptr(), d, c, K, L_, int(bool(codebook_shared)), idx2d.data_ptr(),
+                                            _IDX_DTYPES[idx2d.dtype], n, levels, out.data_ptr(), _stream(idx2d.device))
+        _check(rc, "rqae_hip_decode_gram")
+    return out
 
 
 def gram_configure(fused: int = -1, pipe_chunk: int = -1, proj: int = -1, recon: int = -1, lean_levels: int = -1):

@@ -1715,6 +1715,54 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
                             nullptr);
 }
 
+// RQAE.decode on the matrix-core arm: out = sum_l (W_out[l] codebook[idx_l] + b_out[l]) as the reconstruction kernel computes it
+// (bf16-piece products, fp32 accumulation), the codebook rows gathered by the codes inside the kernel.
+int rqae_hip_decode_gram_supported(int d, int c, int K, int L, int codebook_shared, int levels)
+{
+    if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared) || levels < 1 || levels > L || levels > 8 || d % 16) return 0;
+    const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
+    return pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW <= 160 * 1024 ? 1 : 0;
+}
+
+int rqae_hip_decode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *indices, int idx_dtype,
+                         int64_t n_tokens, int levels, float *out, void *stream)
+{
+#ifdef RQAE_FUSED_QUICK
+    return gfail("tools build: only the fused kernel is compiled in");
+#else
+    if (!rqae_hip_decode_gram_supported(d, c, K, L, codebook_shared, levels))
+        return gfail("decode_gram: unsupported shape d=%d c=%d K=%d L=%d levels=%d (one level group: levels <= 8)", d, c, K, L, levels);
+    if (!packed || !indices || !out) return gfail("decode_gram: null pointer");
+    if (idx_dtype != RQAE_IDX_I64 && idx_dtype != RQAE_IDX_I32 && idx_dtype != RQAE_IDX_U16) return gfail("decode_gram: bad idx_dtype %d", idx_dtype);
+    if (n_tokens < 0) return gfail("decode_gram: negative n_tokens");
+    if (reinterpret_cast<uintptr_t>(out) & 15) return gfail("decode_gram: out must be 16-byte aligned");
+    if (n_tokens == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const GView v = gview(packed, d, c, K, L, codebook_shared ? 1 : 0);
+    const Geom &g = v.g;
+    FusedParams pf;
+    memset(&pf, 0, sizeof(pf));
+    pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = out; pf.cb_f32 = v.cb_f32; pf.codes = indices;
+    pf.n_tokens = n_tokens; pf.tok_pad = pad64(n_tokens); pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c; pf.levels = levels; pf.L = L;
+    pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET; pf.NKSC = g.NKSC; pf.stagger = 0; pf.nks_live = nks_recon(g, levels);
+    long long nb = (n_tokens + F_TILE - 1) / F_TILE;
+    const int ncu = device_cus();
+    if (nb > ncu) nb = ncu;
+    const size_t lds = pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW;
+    auto go = [&](auto kern) -> int {
+        G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pf);
+        G_TRY(hipGetLastError());
+        return 0;
+    };
+#define DEC(CPV) (idx_dtype == RQAE_IDX_I64 ? go(gram_fused_kernel<RQAE_IDX_I64, CPV, true, 4>) \
+                  : idx_dtype == RQAE_IDX_I32 ? go(gram_fused_kernel<RQAE_IDX_I32, CPV, true, 4>) : go(gram_fused_kernel<RQAE_IDX_U16, CPV, true, 4>))
+    const int rc = g.CP == 4 ? DEC(4) : DEC(5);
+#undef DEC
+    return rc;
+#endif
+}
+
 int rqae_hip_gram_configure(int fused, long long pipe_chunk, int proj, int recon)
 {
     Tuning &t = tuning_mut();

@@ -46,6 +46,7 @@ struct FusedParams {
     int ug0;                   // MODE 1: first projection group of this launch (NG groups per launch)
     int nks_live;              // MODE 2: k-steps the levels in use fill (the rest are zero)
     const float *cvf;          // MODE 3: fp32 straight-through values [tok_pad][8 CP]
+    const void *codes;         // MODE 4: code indices [n_tokens][levels] (int64 / int32 / uint16 by the XT parameter: RQAE_IDX_*)
 };
 
 constexpr int F_NW = 8;                 // waves per workgroup
@@ -128,14 +129,14 @@ __device__ __forceinline__ void wave_sync_lds()
 
 // CEQ: c == CP (codebook rows are CP floats apart: aligned float4 row quads)
 // MODE 0: all three phases.  MODE 1: phase A alone (projections to global memory: the first kernel of the three-kernel
-// path).  MODE 2 / 3: phase C alone (its third kernel; operand rows as bf16 pieces from gram_levels_kernel / as fp32 values from
+// path).  MODE 4: phase C alone from code indices (decode; XT then names the index type).  MODE 2 / 3: phase C alone (its third kernel; operand rows as bf16 pieces from gram_levels_kernel / as fp32 values from
 // gram_levels2_kernel).  Same code, same bits.
 template <int XT, int CP, bool CEQ, int MODE = 0>
 __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 {
     using G = FusedGeom<CP>;
     constexpr int GL = G::GL, NG = G::NG, NKS = G::NKS, GB = G::GB, KC = G::KC, STAGE_A = G::STAGE_A, STAGE_C = G::STAGE_C;
-    static_assert(XRaw<XT>::ESZ == 2, "x rows are staged as 128-byte pieces of 64 two-byte elements");
+    static_assert(MODE >= 2 || XRaw<XT>::ESZ == 2, "x rows are staged as 128-byte pieces of 64 two-byte elements");
     constexpr int FPK = NG * 3;                    // W_in fragments per k-step
     constexpr int XP = 4;                          // x pieces per chunk and wave (32 rows x 128 bytes)
     static_assert(A_TT == 2, "32 tokens per wave");
@@ -642,6 +643,29 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                 for (int li = 0; li < GL; ++li)
 #pragma unroll
                     for (int j = 0; j < CP; ++j) cvf[li][j] = flat[li * CP + j];
+            }
+            build_cvB(cvf, trb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (MODE == 4) {
+            // decode (rqae/model.py:236-252): the values are the codebook rows the codes name -- gathered from the fp32 rows in L2,
+            // split here like MODE 3's
+            float cvf[GL][CP];
+            {
+                long long tok = tw0 + tl;
+                tok = tok < tile_end ? tok : tile_end - 1;
+#pragma unroll
+                for (int li = 0; li < GL; ++li) {
+                    long long code = 0;
+                    if (li < levels) {
+                        if constexpr (XT == RQAE_IDX_I64) code = static_cast<const long long *>(p.codes)[tok * levels + li];
+                        else if constexpr (XT == RQAE_IDX_I32) code = static_cast<const int *>(p.codes)[tok * levels + li];
+                        else code = static_cast<const unsigned short *>(p.codes)[tok * levels + li];
+                    }
+                    const float *row = p.cb_f32 + (size_t)code * c;
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) cvf[li][j] = (li < levels && j < c) ? row[j] : 0.0f;
+                }
             }
             build_cvB(cvf, trb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -482,7 +482,12 @@ class RQAE(nn.Module):
         idx = indices.reshape(B * S, NQ)
         if idx.dtype not in (torch.int64, torch.int32, torch.uint16):
             idx = idx.long()
-        out = _native.decode(self.packed_weights(), self._dims(), idx.contiguous(), keep)
+        idx = idx.contiguous()
+        if all(keep) and self._use_gram(B * S, NQ) and _native.decode_gram_supported(self._dims(), True, NQ):
+            # the matrix-core arm's reconstruction kernel fed by the codes: same sum within 1e-6 relative, HBM-write-bound
+            out = _native.decode_gram(self.gram_packed_weights(), self._dims(), True, idx)
+        else:
+            out = _native.decode(self.packed_weights(), self._dims(), idx, keep)
         return out.view(B, S, -1)
 
     # ----------------------------------------------------------------- LLM hook

@@ -230,6 +230,37 @@ def test_gram_c5_streamed_codebook_depth_32():
     print(f"gram arm, C5 depth 32, {n} tokens: {len(rows)} low-margin tokens differ from the exact arm, all adjudicated")
 
 
+def test_gram_decode_matches_the_exact_decode():
+    """RQAE.decode on the matrix-core arm (rqae_hip_decode_gram: the reconstruction kernel fed by the codes) against the exact
+    arm's decode, which is the oracle's and the reference capture's bits (test_hip_parity.py::test_decode): within 1e-6 of the
+    row maximum, for every index type, ragged sizes, and a full-size batch; a layer subset takes the exact kernel."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    mg_, me_ = make_model(cfg, w, "gram"), make_model(cfg, w, "exact")
+    K = cfg["codebook_size"] ** cfg["codebook_dim"]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for n in (1, 17, 255, 256, 257, 4097, 262144):
+        idx = torch.randint(0, K, (1, n, 8), generator=g, dtype=torch.int64).to(DEV)
+        with torch.inference_mode():
+            ref = me_.decode(idx)
+            for dt in (torch.int64, torch.int32, torch.uint16):
+                ix = idx.to(torch.int32).to(torch.int16).view(torch.uint16) if dt == torch.uint16 else idx.to(dt)
+                out = mg_.decode(ix)
+                assert out.shape == ref.shape and out.dtype == torch.float32
+                scale = ref[0].abs().amax(dim=1, keepdim=True)
+                assert float(((out[0] - ref[0]).abs() / scale).max()) < 1e-6, (n, dt)
+            if n == 4097:
+                x_o = oracle.decode(idx[0, :64].cpu().numpy(), w)
+                assert row_rel(mg_.decode(idx)[0, :64].cpu().numpy(), x_o) < 1e-6
+                assert torch.equal(mg_.decode(idx, layers=[0, 2, 5]), me_.decode(idx, layers=[0, 2, 5]))      # subset: exact kernel
+    # what forward returned decodes to what forward reconstructed
+    x = torch.from_numpy(synth.activations(5, 3000, cfg["dim"])).to(DEV).view(1, 3000, -1)
+    with torch.inference_mode():
+        q, idx = mg_(x)
+        dec = mg_.decode(idx)
+    assert float((dec - q).abs().max() / q.abs().max()) < 2e-6
+
+
 def test_gram_deep_shape_and_half_inputs():
     """The pretrained shape's (c 4, K 625: duplicate rows, a zero row, a ragged last row block) first 16 levels -- two
     level groups, so later groups' projections are corrected through the workspace -- in all three input types."""

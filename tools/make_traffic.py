@@ -25,7 +25,7 @@ def short(k):
 def main():
     src = sys.argv[1]
     j = json.load(open(src))
-    ks = {k: v for k, v in j["kernels"].items() if any(t in k for t in ("gram_fused_kernel", "gram_levels_kernel", "gram_project", "gram_reconstruct"))}
+    ks = {k: v for k, v in j["kernels"].items() if any(t in k for t in ("gram_fused_kernel", "gram_levels", "gram_project", "gram_reconstruct"))}
     rd = sum(v.get("hbm_read_bytes", 0.0) for v in ks.values())
     wr = sum(v.get("hbm_write_bytes", 0.0) for v in ks.values())
     tokens = 262144
@@ -35,7 +35,7 @@ def main():
                           for k, v in ks.items()},
            "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --no-cpu-baseline --steps 4 --warmup 2` by tools/pmc.py; "
                    "KiB x 1024, reads x 2 (gfx950 counts 128-byte requests of 16-byte-per-lane streams at 64 bytes).  Above the algorithmic bytes by the "
-                   "intermediates of the three-kernel path (projections 2 x 50 MB, operand rows 151 MB written + 170 MB read) and the weight images' first touch."}
+                   "intermediates of the three-kernel path (projections 50 MB written + read, fp32 straight-through values 42 MB written + read) and the weight images' first touch."}
     json.dump(out, open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w"), indent=1)
     summ = {}
     for k, v in ks.items():

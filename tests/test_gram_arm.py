@@ -261,6 +261,28 @@ def test_gram_decode_matches_the_exact_decode():
     assert float((dec - q).abs().max() / q.abs().max()) < 2e-6
 
 
+@pytest.mark.parametrize("cd,cs,levels,n", [(5, 5, 3, 1500),      # K 3125: CP 5, 196 row tiles -> a ragged last stage, one level group
+                                            (3, 12, 10, 700),     # K 1728: c < CP (padded component), two level groups
+                                            (4, 7, 8, 130)])      # K 2401: 152 row tiles, fewer tokens than a workgroup's tile
+def test_gram_streamed_codebook_shapes(cd, cs, levels, n):
+    """csrc/gram_stream.hpp on shapes around its tiling: stages of 32 row tiles with a ragged tail, c below the padded width,
+    the 4-wave form (few tokens), single and multiple level groups."""
+    cfg = dict(dim=256, codebook_dim=cd, codebook_size=cs, num_quantizers=levels)
+    w = synth.weights(91, cfg["dim"], cd, levels, cs)
+    m = make_model(cfg, w, "gram")
+    K = cs ** cd
+    from rqae_amd import _native
+    assert _native.gram_supported(m._dims(), True) and K > 1100          # past what stays resident in LDS
+    x = synth.activations(40 + cd, n, cfg["dim"])
+    for dt in (torch.float32, torch.bfloat16):
+        q, idx, xs = run(m, x, dt)
+        assert idx.max() < K
+        check_tier2(xs, w, q, idx)
+    with torch.inference_mode():
+        codes = m.encode(torch.from_numpy(x).to(DEV).view(1, n, -1))
+    assert np.array_equal(codes.cpu().numpy().reshape(n, -1), run(m, x, torch.float32)[1])
+
+
 def test_gram_deep_shape_and_half_inputs():
     """The pretrained shape's (c 4, K 625: duplicate rows, a zero row, a ragged last row block) first 16 levels -- two
     level groups, so later groups' projections are corrected through the workspace -- in all three input types."""

@@ -190,6 +190,22 @@ def test_find_examples_full_shard_properties():
 
 
 @pytest.mark.gpu
+def test_find_examples_two_slot_ring():
+    """K = 1024: the level's table slice (64 KB) leaves room for two ring slots, not three -- the other schedule of the kernel."""
+    rng = np.random.default_rng(31)
+    N, S, L, K = 20, 33, 70, 1024
+    codes = rng.integers(0, K, size=(N, S, L), dtype=np.int32)
+    sims16 = rng.standard_normal((L, K, K)).astype(np.float16)
+    layers = [3, 8, 70]
+    f = dict(codes=codes, sims16=sims16, query=codes[7], idx=7, top=4, mid=2, bot=3, layers=layers, n_shards=1)
+    oracle_steps = so.find_examples(sims16, codes, codes[7], 4, 2, 3, layers)
+    for (out, layer, acc), (o_out, _, o_acc, _) in zip(run_engine(f, torch.uint16, as_shards=False), oracle_steps):
+        assert np.array_equal(bits(acc), bits(o_acc)), layer
+        for part in ("top", "middle", "bottom"):
+            assert np.array_equal(np.asarray(out[part]["indices"]), o_out[part]["indices"]), (layer, part)
+
+
+@pytest.mark.gpu
 def test_find_examples_errors():
     from rqae_amd.search import IntensityEngine
 

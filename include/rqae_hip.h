@@ -214,9 +214,11 @@ int rqae_hip_decode_gram(const void *packed, int d, int c, int K, int L, int cod
  *   proj        3: LDS-DMA projection kernel, 2: register-pipelined, 1: first form                               (3)
  *   recon       2: token-stationary reconstruction with 512-byte store rows, 1: weights-stationary               (2) */
 int rqae_hip_gram_configure(int fused, long long pipe_chunk, int proj, int recon);
-/* Level chain of a single level group (levels <= 8): lean = 1 (default; RQAE_GRAM_LEV2 at load) runs the form that hands
- * fp32 straight-through values to the reconstruction kernel, which splits them into bf16 pieces itself; 0 the first
- * form (bf16-piece operand rows written by the level chain); -1 keeps the setting.  Same codes either way. */
+/* Level chain of a single level group (levels <= 8): lean = 2 (default; RQAE_GRAM_LEV2 at load) runs the form that hands
+ * fp32 straight-through values to the reconstruction kernel, which splits them into bf16 pieces itself, with 16 waves per
+ * workgroup (four per SIMD: one wave's serial part runs behind the others' scans; values and codes leave level by level to fit
+ * 128 registers); 1 the same form with 8 waves; 0 the first form (bf16-piece operand rows written by the level chain); -1 keeps
+ * the setting.  Same codes every way. */
 int rqae_hip_gram_configure_levels(int lean);
 int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x,
                                 int x_dtype, int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,

@@ -1192,7 +1192,8 @@ struct Tuning {
     int cap_ab;          // pipelined schedule: CUs for projection + level chain; the reconstruction of the pass before takes the rest
     int fused;           // 1: one persistent kernel where the shape allows it, 0: always the three-kernel form
     int stagger;         // fused kernel: 1 = half first tile on odd workgroups
-    int lev2;            // level chain of one level group: 1 = lean form handing fp32 values to the reconstruction (default), 0 = first form
+    int lev2;            // level chain of one level group: 2 = lean form (fp32 values to the reconstruction) with 16 waves per workgroup
+                         // (default), 1 = lean form with 8 waves, 0 = first form
 };
 Tuning &tuning_mut()
 {
@@ -1210,8 +1211,8 @@ Tuning &tuning_mut()
         if (const char *e = getenv("RQAE_GRAM_PIPE")) { const long long c = atoll(e); v.pipe_chunk = c <= 0 ? 0 : ((c + 255) & ~255LL); }
         v.cap_ab = 160;
         if (const char *e = getenv("RQAE_GRAM_CAP_AB")) { const int c = atoi(e); if (c >= 8) v.cap_ab = c; }
-        v.lev2 = 1;
-        if (const char *e = getenv("RQAE_GRAM_LEV2")) v.lev2 = atoi(e) != 0;
+        v.lev2 = 2;
+        if (const char *e = getenv("RQAE_GRAM_LEV2")) { const int a = atoi(e); v.lev2 = a < 0 || a > 2 ? 1 : a; }
         v.stagger = 0;
         if (const char *e = getenv("RQAE_GRAM_STAGGER")) v.stagger = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
@@ -1545,17 +1546,20 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pl.cvf = reinterpret_cast<float *>(cvimg); pl.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pl.n_tokens = nt; pl.tok_pad = tp; pl.ntiles = (nt + 63) / 64;
             pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c;
-            const size_t lds = lev2_lds_bytes(c, K);
-            long long nb = (pl.ntiles + F_NW - 1) / F_NW;
-            const long long bcap = strict ? ncu : 2LL * ncu;
+            // 16 waves per workgroup (four per SIMD: one wave's serial part behind the others' scans) where the tables leave room
+            const int nw = (tuning().lev2 == 2 && c == g.CP && lev2_lds_bytes(c, K, 16) <= 160 * 1024) ? 16 : F_NW;
+            const size_t lds = lev2_lds_bytes(c, K, nw);
+            long long nb = (pl.ntiles + nw - 1) / nw;
+            const long long bcap = (strict || nw == 16) ? ncu : 2LL * ncu;
             if (nb > bcap) nb = bcap;
             auto go = [&](auto kern) -> int {
                 G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pl);
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nw * 64), lds, s, pl);
                 G_TRY(hipGetLastError());
                 return 0;
             };
             const bool ceq = c == g.CP;
+            if (nw == 16) return g.CP == 4 ? go(gram_levels2_kernel<4, true, 16>) : go(gram_levels2_kernel<5, true, 16>);
             return g.CP == 4 ? (ceq ? go(gram_levels2_kernel<4, true>) : go(gram_levels2_kernel<4, false>))
                              : (ceq ? go(gram_levels2_kernel<5, true>) : go(gram_levels2_kernel<5, false>));
         }
@@ -1775,7 +1779,7 @@ int rqae_hip_gram_configure(int fused, long long pipe_chunk, int proj, int recon
 
 int rqae_hip_gram_configure_levels(int lean)
 {
-    if (lean >= 0) tuning_mut().lev2 = lean != 0;
+    if (lean >= 0) tuning_mut().lev2 = lean > 2 ? 2 : lean;
     return 0;
 }
 

@@ -807,15 +807,15 @@ struct Lev2Params {
     int levels, L, K, KTP, c;
 };
 
-__host__ __device__ inline size_t lev2_lds_bytes(int c, int K)
+__host__ __device__ inline size_t lev2_lds_bytes(int c, int K, int nw = F_NW)
 {
     const int CP = cp_of(c);
     const size_t KTP = (((size_t)(K + 15) / 16 + 3) / 4) * 4, gb = (CP * CP + 3) & ~3;
-    return KTP * 1024 + pad1k(((size_t)K + 64) * c * 4) + F_NW * 4096 + 64 * gb * 4;
+    return KTP * 1024 + pad1k(((size_t)K + 64) * c * 4) + (size_t)nw * 4096 + 64 * gb * 4;
 }
 
-template <int CP, bool CEQ>
-__global__ __launch_bounds__(F_NW * 64) void gram_levels2_kernel(Lev2Params p)
+template <int CP, bool CEQ, int NW = F_NW>
+__global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
 {
     constexpr int GL = 8, GP = ((GL * CP + 15) / 16) * 16, NG = GP / 16, GB = (CP * CP + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -828,15 +828,15 @@ __global__ __launch_bounds__(F_NW * 64) void gram_levels2_kernel(Lev2Params p)
     const unsigned cbf_bytes = (unsigned)pad1k(((size_t)p.K + 64) * c * 4);
     const float *cbf = reinterpret_cast<const float *>(smem + off_cbf);
     char *xch = smem + off_cbf + cbf_bytes + wave * 4096;
-    float *sgram = reinterpret_cast<float *>(smem + off_cbf + cbf_bytes + F_NW * 4096);
+    float *sgram = reinterpret_cast<float *>(smem + off_cbf + cbf_bytes + NW * 4096);
     {   // tables: codebook image + fp32 rows by LDS-DMA, Gram blocks of the group by the threads
         const int npi = p.KTP + (int)(cbf_bytes >> 10);
-        for (int q = wave; q < npi; q += F_NW) {
+        for (int q = wave; q < npi; q += NW) {
             const void *src = q < p.KTP ? static_cast<const void *>(p.cb_img + (size_t)q * 512)
                                         : static_cast<const void *>(reinterpret_cast<const char *>(p.cb_f32) + (size_t)(q - p.KTP) * 1024);
             dma_piece(uniform_ptr(src), lds0 + q * 1024, (unsigned)lane * 16u);
         }
-        for (int i = tid; i < GL * GL * GB; i += F_NW * 64) {
+        for (int i = tid; i < GL * GL * GB; i += NW * 64) {
             const int blk = i / GB, li = blk / GL, li2 = blk - li * GL;
             sgram[i] = (li < p.L && li2 < p.L) ? p.gneg[((size_t)li * p.L + li2) * GB + (i - blk * GB)] : 0.0f;
         }
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_levels2_kernel(Lev2Params p)
     }
     const int wq = (lane >> 2) & 3;
     const int ngrp = p.KTP / 4;
-    for (long long tile = (long long)blockIdx.x * F_NW + wave; tile < p.ntiles; tile += (long long)gridDim.x * F_NW) {
+    for (long long tile = (long long)blockIdx.x * NW + wave; tile < p.ntiles; tile += (long long)gridDim.x * NW) {
         const long long t = tile * 64 + lane;          // < tok_pad
         float Q[GL][CP];
         {
@@ -866,7 +866,8 @@ __global__ __launch_bounds__(F_NW * 64) void gram_levels2_kernel(Lev2Params p)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) Q[li][j] = buf[li * CP + j];
         }
-        float cvh[GL][CP];
+        constexpr bool EARLY = NW > 8;           // 16 waves: 128 registers per lane -- the values leave level by level instead of at the end
+        float cvh[EARLY ? 1 : GL][CP];
         int codes[GL];
         static_for<0, GL>([&](auto li_c) {
             constexpr int li = decltype(li_c)::value;
@@ -1032,12 +1033,18 @@ __global__ __launch_bounds__(F_NW * 64) void gram_levels2_kernel(Lev2Params p)
                 }
                 if (!okq) brow = 0;
                 codes[li] = brow;
+                if constexpr (EARLY) { if (t < p.n_tokens) p.idx[t * levels + li] = (long long)brow; }
                 // ---- straight-through value (rqae/model.py:218-220)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) {
                     const float cv = j < c ? cbf[(size_t)brow * c + j] : 0.0f;
                     const float df = cv - q[j];
-                    cvh[li][j] = q[j] + df;
+                    cvh[EARLY ? 0 : li][j] = q[j] + df;
+                }
+                if constexpr (EARLY) {
+                    float *dst = p.cvf + (size_t)t * (GL * CP) + li * CP;
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) dst[j] = cvh[0][j];
                 }
                 // ---- later levels see the level just applied (every block of the group is staged: zeros past the depth in use)
                 if constexpr (li + 1 < GL) {
@@ -1058,22 +1065,28 @@ __global__ __launch_bounds__(F_NW * 64) void gram_levels2_kernel(Lev2Params p)
 #pragma unroll
                         for (int j = 0; j < CP; ++j)
 #pragma unroll
-                            for (int i = 0; i < CP; ++i) Q[li2][j] = __builtin_fmaf(gbr[cur][j * CP + i], cvh[li][i], Q[li2][j]);
+                            for (int i = 0; i < CP; ++i) Q[li2][j] = __builtin_fmaf(gbr[cur][j * CP + i], cvh[EARLY ? 0 : li][i], Q[li2][j]);
                     }
                 }
             } else {
                 codes[li] = 0;
+                if constexpr (EARLY) {
+                    float *dst = p.cvf + (size_t)t * (GL * CP) + li * CP;
 #pragma unroll
-                for (int j = 0; j < CP; ++j) cvh[li][j] = 0.0f;
+                    for (int j = 0; j < CP; ++j) dst[j] = 0.0f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) cvh[li][j] = 0.0f;
+                }
             }
         });
         // ---- codes and fp32 straight-through values of the tile
-        if (t < p.n_tokens) {
+        if (!EARLY && t < p.n_tokens) {
 #pragma unroll
             for (int li = 0; li < GL; ++li)
                 if (li < levels) p.idx[t * levels + li] = (long long)codes[li];
         }
-        {
+        if constexpr (!EARLY) {
             f32x4 *dst = reinterpret_cast<f32x4 *>(p.cvf + (size_t)t * (GL * CP));
             float flat[GL * CP];
 #pragma unroll

@@ -349,7 +349,7 @@ def test_arm_auto_switches_on_batch_size():
         assert torch.equal(auto(large)[0], gram(large)[0])
 
 
-@pytest.mark.parametrize("variant", ["fused", "pipelined", "first kernels"])
+@pytest.mark.parametrize("variant", ["fused", "pipelined", "first kernels", "lean chain, 8 waves", "first level chain"])
 def test_gram_kernel_variants(variant):
     """Every kernel selection of the arm (rqae_hip_gram_configure) under the same Tier-2 bar, at a size that spans several
     tiles / passes and a ragged end; the defaults are what every other test in this file runs."""
@@ -364,8 +364,12 @@ def test_gram_kernel_variants(variant):
             _native.gram_configure(fused=1)
         elif variant == "pipelined":
             _native.gram_configure(pipe_chunk=16384)
-        else:
+        elif variant == "first kernels":
             _native.gram_configure(proj=2, recon=1)
+        elif variant == "lean chain, 8 waves":
+            _native.gram_configure(lean_levels=1)
+        else:
+            _native.gram_configure(lean_levels=0)
         for dt in (torch.bfloat16, torch.float16, torch.float32):
             q, idx, xs = run(m, x, dt)
             check_tier2(xs[sel], w, q[sel], idx[sel])
@@ -375,7 +379,7 @@ def test_gram_kernel_variants(variant):
         q3, i3, xs = run(m, x[:5000], torch.bfloat16, max_layers=3)
         check_tier2(xs, w, q3, i3, levels=3)
     finally:
-        _native.gram_configure(fused=0, pipe_chunk=0, proj=3, recon=2)
+        _native.gram_configure(fused=0, pipe_chunk=0, proj=3, recon=2, lean_levels=2)
 
 
 def test_operators_match_the_module_bit_for_bit():

@@ -45,7 +45,7 @@ struct FusedParams {
     long long tok_pad;
     int ug0;                   // MODE 1: first projection group of this launch (NG groups per launch)
     int nks_live;              // MODE 2: k-steps the levels in use fill (the rest are zero)
-    const float *cvf;          // MODE 3: fp32 straight-through values [tok_pad][8 CP]
+    const float *cvf;          // MODE 3: fp32 straight-through values, level planes [8][tok_pad][CP]
     const void *codes;         // MODE 4: code indices [n_tokens][levels] (int64 / int32 / uint16 by the XT parameter: RQAE_IDX_*)
 };
 
@@ -626,23 +626,18 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if constexpr (MODE == 3) {
-            // fp32 straight-through values written by gram_levels2_kernel, [token][GL * CP] (zeros past the depth in use): the
+            // fp32 straight-through values written by gram_levels2_kernel, level planes [GL][tok_pad][CP] (zeros past the depth in use): the
             // split into bf16 pieces happens here, on the memory-bound side
             float cvf[GL][CP];
             {
                 long long tok = tw0 + tl;
                 tok = tok < tile_end ? tok : tile_end - 1;
-                const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cvf + (size_t)tok * (GL * CP));
-                float flat[GL * CP];
 #pragma unroll
-                for (int v = 0; v < GL * CP / 4; ++v) {
-                    const f32x4 w = src[v];
-                    flat[4 * v] = w[0]; flat[4 * v + 1] = w[1]; flat[4 * v + 2] = w[2]; flat[4 * v + 3] = w[3];
+                for (int li = 0; li < GL; ++li) {
+                    const float *src = p.cvf + ((size_t)li * p.tok_pad + tok) * CP;
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) cvf[li][j] = src[j];
                 }
-#pragma unroll
-                for (int li = 0; li < GL; ++li)
-#pragma unroll
-                    for (int j = 0; j < CP; ++j) cvf[li][j] = flat[li * CP + j];
             }
             build_cvB(cvf, trb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -801,7 +796,7 @@ struct Lev2Params {
     const float *gneg;         // [L][L][GB]
     const uint16_t *cb_img;    // [KTP][512]
     const float *cb_f32;       // [K + 64][c], whole KiB
-    float *cvf;                // [tok_pad][8 CP]
+    float *cvf;                // [8][tok_pad][CP]: level planes (a wave stores, and the reconstruction loads, along tokens)
     long long *idx;            // [n_tokens][levels]
     long long n_tokens, tok_pad, ntiles;
     int levels, L, K, KTP, c;
@@ -1042,7 +1037,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                     cvh[EARLY ? 0 : li][j] = q[j] + df;
                 }
                 if constexpr (EARLY) {
-                    float *dst = p.cvf + (size_t)t * (GL * CP) + li * CP;
+                    float *dst = p.cvf + ((size_t)li * p.tok_pad + t) * CP;      // a wave's 64 lanes: 64 x CP contiguous floats
 #pragma unroll
                     for (int j = 0; j < CP; ++j) dst[j] = cvh[0][j];
                 }
@@ -1071,7 +1066,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
             } else {
                 codes[li] = 0;
                 if constexpr (EARLY) {
-                    float *dst = p.cvf + (size_t)t * (GL * CP) + li * CP;
+                    float *dst = p.cvf + ((size_t)li * p.tok_pad + t) * CP;
 #pragma unroll
                     for (int j = 0; j < CP; ++j) dst[j] = 0.0f;
                 } else {
@@ -1087,14 +1082,12 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                 if (li < levels) p.idx[t * levels + li] = (long long)codes[li];
         }
         if constexpr (!EARLY) {
-            f32x4 *dst = reinterpret_cast<f32x4 *>(p.cvf + (size_t)t * (GL * CP));
-            float flat[GL * CP];
 #pragma unroll
-            for (int li = 0; li < GL; ++li)
+            for (int li = 0; li < GL; ++li) {
+                float *dst = p.cvf + ((size_t)li * p.tok_pad + t) * CP;
 #pragma unroll
-                for (int j = 0; j < CP; ++j) flat[li * CP + j] = cvh[li][j];
-#pragma unroll
-            for (int v = 0; v < GL * CP / 4; ++v) dst[v] = f32x4{flat[4 * v], flat[4 * v + 1], flat[4 * v + 2], flat[4 * v + 3]};
+                for (int j = 0; j < CP; ++j) dst[j] = cvh[li][j];
+            }
         }
     }
 }

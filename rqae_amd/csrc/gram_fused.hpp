@@ -904,17 +904,17 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                 int bgrp[4];
 #pragma unroll
                 for (int T = 0; T < 4; ++T) { best[T] = -INFINITY; bgrp[T] = 0; }
-                u32x4 an[4];
+                // The fragments of a row-tile group (4 KiB: one ds_read_b128 per tile and lane) are read one group ahead into two
+                // alternating register sets; __builtin_amdgcn_sched_barrier keeps each group's reads above the other group's MFMAs
+                // (left alone hipcc puts a group's reads at the top of its own iteration and the first MFMA waits out the LDS
+                // latency 16 times per level).  Plain loads: hipcc counts lgkmcnt itself.
+                u32x4 fa[4], fb[4];
+                auto ldfrag = [&](u32x4 (&f)[4], int grp) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u32x4 *>(cbl + i * 1024 + lane * 16);
-                for (int grp = 0; grp < ngrp; ++grp) {
+                    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const u32x4 *>(cbl + (grp * 4 + i) * 1024 + lane * 16);
+                };
+                auto scan4 = [&](const u32x4 (&a)[4], int grp) {
                     float mx[4];
-                    u32x4 a[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = an[i];
-                    const int gn = grp + 1 < ngrp ? grp + 1 : grp;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u32x4 *>(cbl + (gn * 4 + i) * 1024 + lane * 16);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         // four independent MFMAs back to back (one per token tile), then their maxima (v_maximum3_f32: a NaN score
@@ -931,10 +931,20 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                     }
 #pragma unroll
                     for (int T = 0; T < 4; ++T) {
-                        const bool up = mx[T] > best[T];
+                        const bool up = mx[T] > best[T];      // (the clamped reload below is never scanned twice as a different group)
                         best[T] = up ? mx[T] : best[T];
                         bgrp[T] = up ? grp : bgrp[T];
                     }
+                };
+                ldfrag(fa, 0);
+                for (int grp = 0; grp < ngrp; grp += 2) {
+                    const int g1 = grp + 1 < ngrp ? grp + 1 : ngrp - 1, g2 = grp + 2 < ngrp ? grp + 2 : ngrp - 1;
+                    ldfrag(fb, g1);
+                    scan4(fa, grp);
+                    __builtin_amdgcn_sched_barrier(0);      // this group's MFMAs stay above the next reads, those reads above the next MFMAs
+                    ldfrag(fa, g2);
+                    scan4(fb, g1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- the four lanes (g) of a token hand their (maximum, group) to the token's own lane
                 wave_sync_lds();

@@ -106,6 +106,32 @@ def test_gram_tile_boundaries(n):
     assert np.array_equal(only.cpu().numpy().reshape(n, -1), idx)       # codes-only call: same codes
 
 
+def test_new_entry_points_reject_bad_arguments():
+    """Error behaviour of this round's C-ABI additions (include/rqae_hip.h): a non-zero return and a message, never a launch."""
+    import ctypes
+    L = _native.lib()
+    vp = ctypes.c_void_p
+    buf = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    bad = [
+        L.rqae_hip_decode_gram(None, 2304, 5, 1024, 8, 1, buf.data_ptr(), 0, 4, 8, buf.data_ptr(), None),            # packed NULL
+        L.rqae_hip_decode_gram(buf.data_ptr(), 2304, 5, 1024, 8, 1, buf.data_ptr(), 7, 4, 8, buf.data_ptr(), None),  # bad index type
+        L.rqae_hip_decode_gram(buf.data_ptr(), 2304, 5, 4096, 32, 1, buf.data_ptr(), 0, 4, 32, buf.data_ptr(), None),  # more than one level group
+        L.rqae_hip_search_query_table(buf.data_ptr(), 8, 625, buf.data_ptr(), 129, 8, 0, 4, buf.data_ptr(), None),   # Q > 128
+        L.rqae_hip_search_query_table(buf.data_ptr(), 8, 625, buf.data_ptr(), 127, 8, 4, 9, buf.data_ptr(), None),   # levels past L
+        L.rqae_hip_search_accumulate(buf.data_ptr(), 0, 16, 8, buf.data_ptr(), 625, 127, 0, 4, buf.data_ptr(), 1, None),   # int64 codes
+        L.rqae_hip_search_accumulate(buf.data_ptr(), 2, 16, 8, buf.data_ptr(), 5000, 127, 0, 4, buf.data_ptr(), 1, None),  # K too large
+        L.rqae_hip_search_accumulate(buf.data_ptr(), 2, 16, 8, buf.data_ptr(), 625, 127, 3, 3, buf.data_ptr(), 1, None),   # empty range
+        L.rqae_hip_search_rank(buf.data_ptr(), 4, 3, 127, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 16, None),       # workspace too small
+        L.rqae_hip_search_gather(buf.data_ptr(), 4, 3, 200, buf.data_ptr(), 2, buf.data_ptr(), None),                      # Q > 128
+    ]
+    assert all(rc != 0 for rc in bad), bad
+    assert L.rqae_hip_last_error()
+    assert L.rqae_hip_decode_gram_supported(2304, 5, 1024, 8, 1, 8) == 1 and L.rqae_hip_decode_gram_supported(2304, 4, 4096, 32, 1, 32) == 0
+    assert L.rqae_hip_search_supported(625, 127) == 1 and L.rqae_hip_search_supported(625, 129) == 0 and L.rqae_hip_search_supported(2000, 64) == 0
+    assert L.rqae_hip_search_rank_workspace_bytes(0, 127) == 0
+    torch.cuda.synchronize()
+
+
 def test_gram_empty_batch_and_errors():
     cfg = synth.CONFIGS["C2"]
     w = synth.weights(1, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])

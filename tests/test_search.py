@@ -206,6 +206,29 @@ def test_find_examples_two_slot_ring():
 
 
 @pytest.mark.gpu
+def test_find_examples_is_repeatable():
+    """Many passes over the same query leave the same bits (a timing-dependent error would differ from pass to pass:
+    DESIGN.md section 10 has the one this round found in another kernel)."""
+    from rqae_amd.search import IntensityEngine
+
+    g = torch.Generator(device="cpu").manual_seed(4)
+    N, S, L, K = 256, 127, 96, 625
+    codes = torch.randint(0, K, (N, S, L), generator=g, dtype=torch.int32)
+    sims16 = (torch.rand((L, K, K), generator=g) * 2 - 1).to(torch.float16)
+    eng = IntensityEngine(sims16, codes, device="cuda:0")
+    layers = [4, 16, 96]
+    ref = None
+    for rep in range(12):
+        accs = []
+        for out, layer in eng.find_examples(idx=9, layers=layers):
+            accs.append((eng.accumulated(S).clone(), out["top"]["indices"].clone()))
+        if ref is None:
+            ref = accs
+        for (a, i), (ra, ri) in zip(accs, ref):
+            assert torch.equal(a.view(torch.int16), ra.view(torch.int16)) and torch.equal(i, ri), rep
+
+
+@pytest.mark.gpu
 def test_find_examples_errors():
     from rqae_amd.search import IntensityEngine
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v)
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SEL | (SEL << 2) | (SEL << 4) | (SEL << 6), 0xf, 0xf, true);
 }
 
-template <typename CT, int ADD = 0>
+template <typename CT>
 __global__ __launch_bounds__(S_NW * 64) void search_accumulate_kernel(AccParams p)
 {
     using CB = CodeBlock<CT>;
@@ -153,7 +153,9 @@ __global__ __launch_bounds__(S_NW * 64) void search_accumulate_kernel(AccParams 
     // every wave issues the same number of pieces per slice (the waits below count them): a wave past the last piece repeats it
     const int PW = (npieces + S_NW - 1) / S_NW;
     auto stage = [&](int li, int slot) {
-        if (p.dbg & 1) { if (li >= p.nbuf - 1) return; }          // measurement only (RQAE_SEARCH_DBG=1): no slice after the first ones
+#ifdef RQAE_SEARCH_TOOLS   /* tools build, measurement only (RQAE_SEARCH_DBG=1): no slice after the first ones -- wrong results */
+        if (p.dbg & 1) { if (li >= p.nbuf - 1) return; }
+#endif
         for (int i = 0; i < PW; ++i) {
             int pc = wave + i * S_NW;
             pc = pc < npieces ? pc : npieces - 1;
@@ -251,15 +253,10 @@ __global__ __launch_bounds__(S_NW * 64) void search_accumulate_kernel(AccParams 
                 for (int ts = 0; ts < S_TS; ++ts)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if constexpr (ADD == 0) {
-                            // fp16 -> fp32 and add in one operation each (v * 1.0 + acc, one rounding: the fp32 sum)
-                            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(acc[ts][2 * e]) : "v"(row[ts][e]));
-                            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[ts][2 * e + 1]) : "v"(row[ts][e]));
-                        } else {
-                            const h16x2 hv = __builtin_bit_cast(h16x2, row[ts][e]);
-                            acc[ts][2 * e] += (float)hv[0];
-                            acc[ts][2 * e + 1] += (float)hv[1];
-                        }
+                        // fp16 -> fp32 and add in one operation each (v * 1.0 + acc, one rounding: the fp32 sum); the cheapest form
+                        // measured (tools/ubench/mix_rate.hip)
+                        asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(acc[ts][2 * e]) : "v"(row[ts][e]));
+                        asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[ts][2 * e + 1]) : "v"(row[ts][e]));
                     }
                 slot = slot + 1 == p.nbuf ? 0 : slot + 1;
             }
@@ -395,10 +392,13 @@ int rqae_hip_search_accumulate(const void *codes, int code_dtype, int64_t n_toke
     AccParams p;
     p.codes = codes; p.tq = static_cast<const __half *>(table); p.acc = static_cast<__half *>(acc); p.NT = n_tokens; p.Ltot = L;
     p.KP = ((K + 15) / 16) * 16; p.l0 = l0; p.l1 = l1; p.first = first ? 1 : 0; p.nbuf = pick_nbuf(p.KP);
+    p.dbg = 0;
+#ifdef RQAE_SEARCH_TOOLS   /* tools build: ring depth and the no-refill ablation (profiles/r02_search_ring_and_dma_ablation.txt) */
     static const int dbg = getenv("RQAE_SEARCH_DBG") ? atoi(getenv("RQAE_SEARCH_DBG")) : 0;
     static const int nbuf_env = getenv("RQAE_SEARCH_NBUF") ? atoi(getenv("RQAE_SEARCH_NBUF")) : 0;
     p.dbg = dbg;
     if (nbuf_env >= 2 && (size_t)nbuf_env * p.KP * 64 <= 160 * 1024) p.nbuf = nbuf_env;
+#endif
     const size_t lds = (size_t)p.nbuf * p.KP * 64;
     const dim3 grid((unsigned)((n_tokens + S_TOK - 1) / S_TOK), (unsigned)((Q + S_QW - 1) / S_QW));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -408,8 +408,6 @@ int rqae_hip_search_accumulate(const void *codes, int code_dtype, int64_t n_toke
         S_TRY(hipGetLastError());
         return 0;
     };
-    static const int add_form = getenv("RQAE_SEARCH_ADD") ? atoi(getenv("RQAE_SEARCH_ADD")) : 0;
-    if (add_form) return code_dtype == RQAE_IDX_U16 ? go(search_accumulate_kernel<uint16_t, 1>) : go(search_accumulate_kernel<int32_t, 1>);
     return code_dtype == RQAE_IDX_U16 ? go(search_accumulate_kernel<uint16_t>) : go(search_accumulate_kernel<int32_t>);
 }
 

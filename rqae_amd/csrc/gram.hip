@@ -1471,7 +1471,10 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         ProjParams pa;
         pa.x = static_cast<const char *>(x) + (size_t)t0 * d * xs;
         pa.win_img = v.win_img; pa.P = P; pa.dump = dump; pa.n_tokens = nt; pa.tok_pad = tp; pa.d = d; pa.NOG = g.NOG; pa.KSA = g.KSA;
-        if (tuning().proj == 3 && x_dtype != RQAE_X_F32 && d % 64 == 0) {
+        // the LDS-DMA projection covers 3 (c = 5) or 2 (c <= 4) output groups per launch and re-reads x for every launch: it is the
+        // faster form when one launch is all there is; deeper shapes take the register-pipelined kernel (C5, 8 groups: 0.71 vs 0.93 ms)
+        const int ngf_all = g.CP == 4 ? FusedGeom<4>::NG : FusedGeom<5>::NG;
+        if (tuning().proj == 3 && x_dtype != RQAE_X_F32 && d % 64 == 0 && g.NOG <= ngf_all) {
             FusedParams pf;
             memset(&pf, 0, sizeof(pf));
             pf.x = pa.x; pf.win_img = v.win_img; pf.P = P; pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c;

@@ -1147,9 +1147,9 @@ __global__ __launch_bounds__(NW * 64) void gram_reconstruct_kernel(RecParams p)
     u32x4 BX[TT][NKS], BY[TT][NKS];
     long long pi = (long long)lq * NW + wave;
     if (xcd + 8 * pi >= p.npairs) return;
-    if constexpr (TT * NKS > 16) {
-        // two register sets of cv pieces no longer fit (hipcc would spill asm-loaded registers before their wait): one set,
-        // loaded and waited for per group
+    if constexpr (TT * NKS >= 16 || NW == 16) {
+        // two register sets of cv pieces no longer fit without spills (and hipcc may spill an asm-loaded register before its wait):
+        // one set, loaded and waited for per group
         for (; xcd + 8 * pi < p.npairs; pi += stride) {
             loadB(BX, xcd + 8 * pi);
             waitB(BX, std::integral_constant<int, 0>{});

@@ -522,6 +522,16 @@ __device__ __forceinline__ void dma_piece(const void *g_uniform, unsigned lds_ad
                  : "memory");
 }
 
+// the same piece with the non-temporal hint: the x stream is read once and should not push the weight images out of L2 / MALL
+__device__ __forceinline__ void dma_piece_nt(const void *g_uniform, unsigned lds_addr, unsigned lane_byte_off)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(g_uniform), "s"(lds_addr)
+                 : "memory");
+}
+
 // ABL: compile-time ablation bits for tools/ builds (-DRQAE_GRAM_ABLATE; 0 in the product): 1 = no MFMAs, 2 = no weight
 // DMA, 4 = no barrier, 8 = no fragment reads from LDS
 template <int XT, int ABL = 0>

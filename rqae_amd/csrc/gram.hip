@@ -1481,32 +1481,41 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         ProjParams pa;
         pa.x = static_cast<const char *>(x) + (size_t)t0 * d * xs;
         pa.win_img = v.win_img; pa.P = P; pa.dump = dump; pa.n_tokens = nt; pa.tok_pad = tp; pa.d = d; pa.NOG = g.NOG; pa.KSA = g.KSA;
-        // the LDS-DMA projection covers 3 (c = 5) or 2 (c <= 4) output groups per launch and re-reads x for every launch: it is the
-        // faster form when one launch is all there is; deeper shapes take the register-pipelined kernel (C5, 8 groups: 0.71 vs 0.93 ms)
-        const int ngf_all = g.CP == 4 ? FusedGeom<4>::NG : FusedGeom<5>::NG;
-        if (tuning().proj == 3 && x_dtype != RQAE_X_F32 && d % 64 == 0 && g.NOG <= ngf_all) {
+        // the LDS-DMA projection covers 3 (c = 5) or 2 (c <= 4) output groups per workgroup; deeper shapes launch ny workgroups per token
+        // tile, placed on one XCD so that the tile's x is read from HBM once (RQAE_GRAM_PROJ=2: the register-pipelined kernel instead)
+        if (tuning().proj == 3 && x_dtype != RQAE_X_F32 && d % 64 == 0) {
             FusedParams pf;
             memset(&pf, 0, sizeof(pf));
             pf.x = pa.x; pf.win_img = v.win_img; pf.P = P; pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c;
             pf.levels = levels; pf.L = L; pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET; pf.NKSC = g.NKSC; pf.stagger = 0; pf.dump = dump;
             pf.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768);
-            long long nb = (nt + F_TILE - 1) / F_TILE;
-            if (nb > ncu) nb = ncu;
             const int ngf = g.CP == 4 ? FusedGeom<4>::NG : FusedGeom<5>::NG;
             const size_t lds = g.CP == 4 ? FusedGeom<4>::LDS_A : FusedGeom<5>::LDS_A;
-            for (int ug0 = 0; ug0 < g.NOG; ug0 += ngf) {
-                pf.ug0 = ug0;
-                auto go = [&](auto kern) -> int {
-                    G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pf);
-                    G_TRY(hipGetLastError());
-                    return 0;
-                };
-                int rc;
-                if (g.CP == 4) rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 4, true, 1>);
-                else rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 5, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 5, true, 1>);
-                if (rc) return rc;
+            const int ny = (g.NOG + ngf - 1) / ngf;
+            const long long ntl = (nt + F_TILE - 1) / F_TILE;
+            long long nb;
+            if (ny > 1) {
+                long long gx = (ncu / ny) & ~7LL;                 // tiles in flight: a multiple of 8 (one id residue per XCD)
+                if (gx < 8) gx = 8;
+                const long long need = (ntl + 7) & ~7LL;
+                if (gx > need) gx = need;
+                nb = gx * ny;
+                pf.ny = ny;
+            } else {
+                nb = ntl < ncu ? ntl : ncu;
+                pf.ny = 1;
             }
+            pf.ug0 = 0;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pf);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            int rc;
+            if (g.CP == 4) rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 4, true, 1>);
+            else rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 5, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 5, true, 1>);
+            if (rc) return rc;
         } else if (tuning().proj >= 2 && g.KSA % 4 == 0) {
             const unsigned ny = (unsigned)((g.NOG + 2) / 3);
             long long gx = (nt + A2_NW * 16 * A_TT - 1) / (A2_NW * 16 * A_TT);     // persistent: one workgroup per CU walks the tiles

@@ -44,6 +44,7 @@ struct FusedParams {
     const unsigned *cvimg;     // MODE 2 reads the reconstruction operand rows [k-step][tok_pad][16 dwords]
     long long tok_pad;
     int ug0;                   // MODE 1: first projection group of this launch (NG groups per launch)
+    int ny;                    // MODE 1: > 1 = one launch covers ny blocks of NG groups; the ny workgroups of a tile share an XCD
     int nks_live;              // MODE 2: k-steps the levels in use fill (the rest are zero)
     const float *cvf;          // MODE 3: fp32 straight-through values, level planes [8][tok_pad][CP]
     const void *codes;         // MODE 4: code indices [n_tokens][levels] (int64 / int32 / uint16 by the XT parameter: RQAE_IDX_*)
@@ -168,10 +169,25 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 
     const int nchunks = p.KSA / KC;
     const int wq = (tl >> 2) & 3;
-    const long long Gn = gridDim.x;
+    long long Gn = gridDim.x, tile_first = blockIdx.x;
+    int ug0 = p.ug0;
+    bool x_shared = false;
+    if constexpr (MODE == 1) {
+        if (p.ny > 1) {
+            // XCD-aware mapping: consecutive workgroup ids go round the 8 XCDs, so ids that are equal mod 8 share an L2.  The ny
+            // workgroups that take the same token tile through different output groups get such ids and run at the same time:
+            // the tile's x comes from HBM once and from that XCD's L2 ny - 1 times (no non-temporal hint on it then).
+            const unsigned bid = blockIdx.x, xcd = bid & 7u, within = bid >> 3;
+            const unsigned ysel = within % (unsigned)p.ny;
+            Gn = gridDim.x / (unsigned)p.ny;
+            tile_first = (within / (unsigned)p.ny) * 8u + xcd;
+            ug0 = p.ug0 + (int)ysel * NG;
+            x_shared = true;
+        }
+    }
 
     int tord = 0;
-    for (long long tile = blockIdx.x; ftile_off(tile, Gn, p.stagger) < p.n_tokens; tile += Gn, ++tord) {
+    for (long long tile = tile_first; ftile_off(tile, Gn, p.stagger) < p.n_tokens; tile += Gn, ++tord) {
         const long long tile0 = ftile_off(tile, Gn, p.stagger);
         long long tile_end = ftile_off(tile + 1, Gn, p.stagger);      // rows past it belong to another tile: never stored
         tile_end = tile_end < p.n_tokens ? tile_end : p.n_tokens;
@@ -209,8 +225,13 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 #else
                 const void *xb = uniform_ptr(xtile + (size_t)cc * 128);
 #endif
+                if (x_shared) {
 #pragma unroll
-                for (int pc = 0; pc < XP; ++pc) dma_piece_nt(xb, lds0 + off_xw + slot * F_XSLOT + pc * 1024, voff[pc]);
+                    for (int pc = 0; pc < XP; ++pc) dma_piece(xb, lds0 + off_xw + slot * F_XSLOT + pc * 1024, voff[pc]);
+                } else {
+#pragma unroll
+                    for (int pc = 0; pc < XP; ++pc) dma_piece_nt(xb, lds0 + off_xw + slot * F_XSLOT + pc * 1024, voff[pc]);
+                }
                 for (int q = wave; q < KC * FPK; q += F_NW) {
                     const int k = q / FPK, f = q - k * FPK;
 #ifdef FQ_NOW   /* tools build: every W piece re-reads the image's first KiB */
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                     const int ks = cc * KC + k;          // < KSA: the host sends only d % (32 KC) == 0 here
 #endif
                     int fu = f / 3;                      // groups past the last one repeat it (MODE 1, never stored)
-                    fu = (MODE == 1 ? p.ug0 : 0) + fu;
+                    fu = (MODE == 1 ? ug0 : 0) + fu;
                     fu = fu < p.NOG ? fu : p.NOG - 1;
                     dma_piece(uniform_ptr(p.win_img + (((size_t)ks * p.NOG + fu) * 3 + (f % 3)) * 512), lds0 + slot * STAGE_A + (k * FPK + f) * 1024, lane16);
                 }
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 #pragma unroll
                 for (int T = 0; T < A_TT; ++T) {
                     const long long tok = tw0 + 16 * T + n;
-                    if (tok < tile_end && p.ug0 + u < p.NOG) *reinterpret_cast<f32x4 *>(p.P + (((size_t)(p.ug0 + u) * p.tok_pad + tok) * 16 + 4 * g)) = acc[u][T];
+                    if (tok < tile_end && ug0 + u < p.NOG) *reinterpret_cast<f32x4 *>(p.P + (((size_t)(ug0 + u) * p.tok_pad + tok) * 16 + 4 * g)) = acc[u][T];
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();     // the rings are free for the next tile

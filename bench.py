@@ -2,6 +2,7 @@
 """Benchmark of the RQAE encode hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--tokens T] [--arm gram|exact|auto] [--codes-only]
+                    [--spinup-ms MS] [--no-extra-legs] [--no-parity]
 
 A "step" is one RQAE.forward (codes + reconstruction, depth 8) over one batch of synthetic Gemma-2-2B-shaped
 activations already resident in HBM.  N = 1: BASELINE.json configs[1] -- 262144 tokens x d=2304 in bf16, K=1024 (c=5),
@@ -9,6 +10,15 @@ depth 8.  N > 1: configs[2]'s sharding -- every rank encodes its own 524288-toke
 replicated, no collective on the data path: weak scaling.  `python bench.py --gpus N` launches its own ranks (one
 process per GPU, RCCL process group for the barrier and the MAX over ranks); under torch.distributed.run it uses the
 ranks it is given.  Rank 0 prints ONE JSON line.
+
+What the line holds besides the contract's fields:
+  * `spinup_ms` / `spinup_steps`: an untimed, disclosed run of the same step BEFORE the W warm-up steps (clocks and caches
+    settle; the K timed steps are still exactly K, bracketed by barrier + synchronize);
+  * `step_ms`: first / min / median / max of the per-step HIP-event times inside the timed region;
+  * `legs`: the same measurement protocol repeated in-process at other batch sizes -- 524288 tokens per GPU (configs[2]'s
+    shard) and, at N = 1, north_star's 1048576 tokens (`roofline.at_1M`) -- so 1 -> N ratios can be taken at equal per-GPU work;
+  * `parity`: after the timed region, a slice of the timed batch through the CPU oracle (codes compared token by token);
+  * `roofline.traffic_source`: where `traffic` comes from (a committed rocprofv3 --pmc pass of the same sources, replayed).
 """
 import argparse
 import hashlib
@@ -24,8 +34,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CFG = dict(dim=2304, codebook_dim=5, codebook_size=4, num_quantizers=8)  # K = 4**5 = 1024
-WORKLOAD_1 = "C2: Gemma-2-2B layer-12 residual stream (synthetic), 256k tokens, d=2304, K=1024, depth=8, bf16 in"
-WORKLOAD_N = "C3: same d/K/depth, 512k tokens per GPU token-sharded (4M over 8 GPUs), codebooks replicated, no collective"
+
+
+def workload_name(tokens, world):
+    """config.workload for the batch actually timed (BASELINE.json configs[1] / configs[2] when the sizes are theirs)."""
+    shape = "d=2304, K=1024, depth=8, bf16 in"
+    if world == 1 and tokens == 262144:
+        return f"C2: Gemma-2-2B layer-12 residual stream (synthetic), 256k tokens, {shape}"
+    if world > 1 and tokens == 524288:
+        return (f"C3: same d/K/depth as C2, 512k tokens per GPU token-sharded ({tokens * world // 1048576}M over {world} GPUs), "
+                "codebooks replicated, no collective")
+    return (f"C2 shape at a non-default batch: Gemma-2-2B layer-12 residual stream (synthetic), {tokens} tokens per GPU x {world} GPU(s), "
+            f"{shape}")
+
 
 # algorithmic work per token (SURVEY.md 8(d), DESIGN.md section 5)
 D, C, K, L = 2304, 5, 1024, 8
@@ -40,6 +61,8 @@ PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # matrix-core arm: bf16 MFMA flops actually issued per token (every fp32 operand as 3 bf16 pieces, 6 kept products per
 # component in the cosine and reconstruction contractions)
 GRAM_MFMA_FLOPS_PER_TOKEN = 2 * D * 48 * 3 + L * 2 * K * 32 + 2 * D * 256
+
+PROFILE_ROUND = "r03"     # profiles/<round>_traffic.json, <round>_pmc_summary.json: the committed counter passes of this round
 
 KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
 
@@ -94,6 +117,39 @@ def cpu_baseline(w, target_seconds=12.0):
                       "(BASELINE.md section 2: 4.3 k tok/s on 8 threads)"}
 
 
+def parity_check(np, torch, model, x, w, gram, codes_only, n_check=4096):
+    """After the timed region: the first `n_check` tokens of the timed batch through the product path once more and through the
+    CPU oracle (the checker, never the thing measured).  Exact arm: every code must equal the oracle's.  Matrix-core arm:
+    SURVEY 8(c) Tier 2 -- codes equal wherever the oracle's top-1/top-2 margin is >= 1e-5; tokens that differ are counted
+    (`listed_low_margin`), and none may differ at a larger margin (`mismatch_at_margin_ge_1e-5` must be 0)."""
+    import oracle
+
+    n = min(n_check, x.shape[1])
+    xs = x[:, :n]
+    with torch.inference_mode():
+        if codes_only:
+            idx, q = model.encode(xs), None
+        else:
+            q, idx = model(xs)
+    torch.cuda.synchronize()
+    xf = xs.float().cpu().numpy().reshape(n, -1)
+    q_o, idx_o, mg = oracle.forward(xf, w, want_margins=True)
+    idx = idx.cpu().numpy().reshape(n, -1)
+    differ = (idx != idx_o).any(axis=1)
+    bad = differ & (mg.min(axis=1) >= 1e-5)
+    out = {"tokens_checked": int(n), "arm": "gram" if gram else "exact", "tokens_with_other_codes": int(differ.sum()),
+           "listed_low_margin": int((differ & ~bad).sum()), "mismatch_at_margin_ge_1e-5": int(bad.sum()),
+           "oracle": "oracle/rqae_oracle.c (pinned to captures of the reference, tests/test_oracle_golden.py)"}
+    if q is not None:
+        same = ~differ
+        qg = q.cpu().numpy().reshape(n, -1)
+        rel = np.abs(qg[same] - q_o[same]).max(axis=1) / np.abs(q_o[same]).max(axis=1)
+        out["recon_max_rel_err"] = float(rel.max()) if rel.size else 0.0
+    out["ok"] = bool(out["mismatch_at_margin_ge_1e-5"] == 0 and (gram or out["tokens_with_other_codes"] == 0)
+                     and out.get("recon_max_rel_err", 0.0) < 1e-5)
+    return out
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -128,6 +184,10 @@ def main():
                     help="gram = matrix-core arm (Tier-2 parity, the fast path); exact = canonical fp32 order (bit-exact)")
     ap.add_argument("--codes-only", action="store_true", help="time RQAE.encode (no reconstruction written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup-ms", type=float, default=300.0,
+                    help="untimed run of the same step before the warm-up steps (disclosed as spinup_ms in the line); 0 = none")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the 524288- and 1048576-token legs")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle check of a 4096-token slice")
     ap.add_argument("--stub", action="store_true", help="CPU/gloo rehearsal of the multi-rank orchestration (tests only)")
     args = ap.parse_args()
 
@@ -179,7 +239,6 @@ def main():
     model = RQAE(**CFG, arm=args.arm).eval()
     model.load_state_dict(synth.state_dict_from_weights(w), strict=True)
     model = model.to(device)
-    x = synth_batch(torch, tokens, device, seed=1000 + rank).view(1, tokens, CFG["dim"])
     fn = model.encode if args.codes_only else model.forward
     gram = model._use_gram(tokens, L)
 
@@ -188,52 +247,105 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    evs = []
+    def measure(n_tok, steps, warmup, spinup_ms):
+        """The contract's protocol on one batch size: [spin-up, disclosed] W warm-up steps, barrier + synchronize, EXACTLY
+        `steps` timed steps, barrier + synchronize; MAX over ranks.  Every step is also bracketed by HIP events on the stream
+        the kernels are launched on."""
+        x = synth_batch(torch, n_tok, device, seed=1000 + rank).view(1, n_tok, CFG["dim"])
+        evs = []
 
-    def step():
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()              # same stream the kernels are launched on (torch's current stream)
-        fn(x)
-        b.record()
-        evs.append((a, b))
+        def step():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()              # same stream the kernels are launched on (torch's current stream)
+            fn(x)
+            b.record()
+            evs.append((a, b))
 
-    with torch.inference_mode():
-        elapsed = sharding.timed_steps(step, args.steps, args.warmup, barrier)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[args.warmup:]]))
-    per_rank = [elapsed]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per_rank = [float(v.item()) for v in allt]
-    elapsed = sharding.max_over_ranks(elapsed, dist, device)
+        spin_steps, spin_s = 0, 0.0
+        with torch.inference_mode():
+            if spinup_ms > 0:
+                t0 = time.perf_counter()
+                while (time.perf_counter() - t0) * 1e3 < spinup_ms:
+                    for _ in range(8):
+                        fn(x)
+                    torch.cuda.synchronize()
+                    spin_steps += 8
+                spin_s = time.perf_counter() - t0
+            elapsed = sharding.timed_steps(step, steps, warmup, barrier)
+        ev_ms = [a.elapsed_time(b) for a, b in evs[warmup:]]
+        per_rank = [elapsed]
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank = [float(v.item()) for v in allt]
+        elapsed = sharding.max_over_ranks(elapsed, dist, device)
+        return {"x": x, "elapsed": elapsed, "per_rank": per_rank, "ev_ms": ev_ms, "spinup_steps": spin_steps,
+                "spinup_ms": spin_s * 1e3}
+
+    def leg_summary(n_tok, m, steps):
+        bytes_tok = BYTES_PER_TOKEN_CODES if args.codes_only else BYTES_PER_TOKEN
+        ms = m["elapsed"] / steps * 1e3
+        return {"tokens_per_gpu_per_step": n_tok, "steps": steps, "ms_per_step": ms,
+                "value": sharding.aggregate_throughput(n_tok, world, steps, m["elapsed"]),
+                "hbm_frac_per_gpu": n_tok * bytes_tok / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "step_ms": step_stats(m["ev_ms"])}
+
+    def step_stats(ev_ms):
+        return {"first": ev_ms[0], "min": float(np.min(ev_ms)), "median": float(np.median(ev_ms)), "max": float(np.max(ev_ms)),
+                "mean": float(np.mean(ev_ms))}
+
+    main_m = measure(tokens, args.steps, args.warmup, args.spinup_ms)
+    x = main_m["x"]
+    elapsed, per_rank = main_m["elapsed"], main_m["per_rank"]
+    kern_ms = float(np.mean(main_m["ev_ms"]))
+
+    # ---- further legs of the same protocol (every rank takes part: barriers and the MAX are collective)
+    legs = {}
+    if not args.no_extra_legs and not args.tokens:
+        for name, n_tok in (("262144", 262144), ("524288", 524288)) + ((("1048576", 1048576),) if world == 1 else ()):
+            if n_tok == tokens:
+                legs[name] = leg_summary(n_tok, main_m, args.steps)
+                continue
+            m = measure(n_tok, args.steps, args.warmup, 0.0)
+            del m["x"]
+            legs[name] = leg_summary(n_tok, m, args.steps)
+        torch.cuda.empty_cache()
 
     if rank == 0:
         value = sharding.aggregate_throughput(tokens, world, args.steps, elapsed)
         bytes_tok = BYTES_PER_TOKEN_CODES if args.codes_only else BYTES_PER_TOKEN
         tok_per_s_kernel = tokens / (kern_ms * 1e-3)
         gbs = tok_per_s_kernel * bytes_tok / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        traffic, traffic_source = None, None
+        tname = f"profiles/{PROFILE_ROUND}_traffic.json"
+        tpath = os.path.join(ROOT, tname)
         if os.path.exists(tpath) and not args.codes_only:
             try:
                 tj = json.load(open(tpath))
                 # measured by tools/pmc.py for THIS build and THIS launch shape, or not reported
                 if tj.get("tokens") == tokens and tj.get("arm") == ("gram" if gram else "exact") and tj.get("sources_sha256_16") == sources_hash():
                     traffic = tj["hbm_bytes_per_step"]
+                    traffic_source = (f"{tname} (replayed: separate rocprofv3 --pmc passes of this command on these kernel sources, "
+                                      "FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md; not measured in this run)")
             except Exception:
                 traffic = None
+        if traffic is None:
+            traffic_source = f"none: no {tname} for these kernel sources and this launch shape"
         if gram:
             roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                    "traffic": traffic, "launch": "one forward = 3 kernels back to back on one stream (projection, level chain, "
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "launch": "one forward = 3 kernels back to back on one stream (projection, level chain, "
                     "reconstruction)", "launch_ms": kern_ms, "bytes_per_token": bytes_tok,
+                    "frac_from_ms_per_step": tokens * bytes_tok / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
                     "mfma_bf16_TFLOPs": tok_per_s_kernel * GRAM_MFMA_FLOPS_PER_TOKEN / 1e12,
                     "mfma_bf16_frac": tok_per_s_kernel * GRAM_MFMA_FLOPS_PER_TOKEN / 1e12 / PEAK_BF16_TFLOPS,
                     "algorithmic_fp32_TFLOPs": tok_per_s_kernel * FLOPS_PER_TOKEN / 1e12}
             try:    # MFMA-busy and per-kernel counters: measured by tools/pmc.py for THIS build (same source hash) or absent
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+                pj = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
                 if traffic is not None:
                     roof["mfma_busy_frac_by_kernel"] = {k: round(v["mfma_busy_frac"], 3) for k, v in pj["kernels"].items() if "mfma_busy_frac" in v}
+                    roof["mfma_busy_source"] = f"profiles/{PROFILE_ROUND}_pmc_summary.json (replayed)"
             except Exception:
                 pass
             try:
@@ -245,7 +357,7 @@ def main():
                     # the dominant kernel on its own: the reconstruction writes 4 d bytes per token (its algorithmic bytes)
                     rms = roof["kernel_ms"]["reconstruct"]
                     rg = tokens * 4.0 * D / (rms * 1e-3) / 1e9
-                    roof["dominant_kernel"] = {"name": "reconstruct (gram_fused_kernel<.., 2>)", "ms": rms, "algorithmic_bytes": tokens * 4 * D,
+                    roof["dominant_kernel"] = {"name": "reconstruct (gram_fused_kernel<.., 3>)", "ms": rms, "algorithmic_bytes": tokens * 4 * D,
                                                "achieved_GBs": rg, "frac": rg / PEAK_HBM_GBS}
             except Exception as e:  # measurement extra only
                 roof["kernel_ms"] = f"unavailable: {e}"
@@ -253,16 +365,22 @@ def main():
             flops_tok = FLOPS_PER_TOKEN_CODES_EXACT if args.codes_only else FLOPS_PER_TOKEN
             tflops = tok_per_s_kernel * flops_tok / 1e12
             roof = {"bound": "fp32-valu", "achieved": tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / PEAK_F32_TFLOPS, "traffic": traffic, "launch_ms": kern_ms, "flops_per_token": flops_tok,
+                    "frac": tflops / PEAK_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "launch_ms": kern_ms,
+                    "flops_per_token": flops_tok,
                     "flops_per_token_survey_8d": FLOPS_PER_TOKEN,
                     "frac_survey_8d": tok_per_s_kernel * FLOPS_PER_TOKEN / 1e12 / PEAK_F32_TFLOPS,
                     "hbm_achieved_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "bytes_per_token": bytes_tok}
+        if "1048576" in legs:
+            roof["at_1M"] = {k: legs["1048576"][k] for k in ("tokens_per_gpu_per_step", "ms_per_step", "value", "step_ms")}
+            roof["at_1M"]["frac"] = legs["1048576"]["hbm_frac_per_gpu"]
         line = {
             "metric": "tokens encoded/sec, d=2304, K=1024, depth=8",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD_1 if world == 1 else WORKLOAD_N, "tokens_per_gpu_per_step": tokens,
+            "spinup_ms": main_m["spinup_ms"], "spinup_steps": main_m["spinup_steps"],
+            "step_ms": step_stats(main_m["ev_ms"]),
+            "config": {"workload": workload_name(tokens, world), "tokens_per_gpu_per_step": tokens,
                        "outputs": "codes int64" + ("" if args.codes_only else " + reconstruction fp32"),
                        "sharding": f"token-sharded x{world}, weights replicated, no collective",
                        "world_size_seen": dist.get_world_size() if dist is not None else 1,
@@ -273,6 +391,12 @@ def main():
                        else "exact: canonical fp32 order, bit-equal to the CPU oracle; " + _native.kernel_info(D, C, K, L)},
             "roofline": roof,
         }
+        if legs:
+            line["legs"] = {"note": "same protocol (W warm-up, K timed steps, barrier + synchronize, MAX over ranks) at other per-GPU "
+                                    "batch sizes; `value` = whole-job tokens/s; take 1 -> N ratios at equal tokens_per_gpu_per_step",
+                            **legs}
+        if not args.no_parity:
+            line["parity"] = parity_check(np, torch, model, x, w, gram, args.codes_only)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(line), flush=True)

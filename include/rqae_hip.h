@@ -29,12 +29,23 @@
 extern "C" {
 #endif
 
-#define RQAE_HIP_ABI_VERSION 2
+#define RQAE_HIP_ABI_VERSION 3
 
 /* element type of the activation matrix x */
 enum { RQAE_X_F32 = 0, RQAE_X_BF16 = 1, RQAE_X_F16 = 2 };
 /* element type of a code-index matrix handed to decode */
 enum { RQAE_IDX_I64 = 0, RQAE_IDX_I32 = 1, RQAE_IDX_U16 = 2 };
+
+/*
+ * Status word.  Entry points that gather rows by caller-supplied code indices take `int32_t *status`: a DEVICE int32 (or
+ * NULL) into which the kernels OR the bits below when they meet bad input -- instead of faulting, asserting or reading out of
+ * bounds.  The kernels never clear it; the caller zeroes it, reads it back after the stream work (or lazily) and turns a set
+ * bit into its own error.  The reference raises a recoverable IndexError for such input (rqae/model.py:234,
+ * rqae/feature.py:120, demo/server/server.py:55): rqae_amd/_native.py raises IndexError from this word and the process
+ * lives on.  A flagged call's output rows for the bad codes are those of row 0 (decode) or unspecified finite values
+ * (intensity / search); every other row is unaffected.
+ */
+#define RQAE_STATUS_CODE_RANGE 1    /* a code index outside its codebook / table / dataset */
 
 int rqae_hip_abi_version(void);
 
@@ -87,12 +98,11 @@ int rqae_hip_quantize(const float *p, int64_t n, int c, int K, const float *code
  * It is an error if no level is selected (the reference returns None; the host
  * mirror handles that case before calling).
  */
-/* PRECONDITION for every entry point that takes code indices (rqae_hip_decode, rqae_hip_intensity): 0 <= code < K for every
- * element read.  The kernels gather codebook / table rows by these values without a range check (the reference raises
- * IndexError); the Python mirror asserts it on the device (rqae_amd/_native.py: check_codes). */
+/* Codes: -K <= code < K as in torch indexing (rqae/model.py:234: a negative code counts from the last row); any other value
+ * is read as row 0 and sets RQAE_STATUS_CODE_RANGE in *status (the reference raises IndexError). */
 int rqae_hip_decode(const void *packed, int d, int c, int K, int L, const void *indices,
                     int idx_dtype, int64_t n_tokens, int idx_levels, const uint8_t *level_mask,
-                    float *out, void *stream);
+                    float *out, int32_t *status, void *stream);
 
 /* RQAE.decode_from_codebook_values (rqae/model.py:236-248): cv [n_tokens][nq][c] fp32. */
 int rqae_hip_decode_values(const void *packed, int d, int c, int K, int L, const float *cv,
@@ -134,7 +144,8 @@ int rqae_hip_gemma_denorm_patch(const float *q_out, const float *norm_weight, co
  *       wcum[m]     = layer_weights[:M].cumsum()[m] in torch-CPU's order (fp32 accumulator, fp16 prefixes)
  *   rqae_hip_intensity:
  *       out[n][j] = fp16( fp16( sum_{m <= layers[j]} fp16(table[m][code[n][m]] * w[m]) ) / wcum[layers[j]] )
- *       indices [n_tokens][nq] idx_dtype (RQAE_IDX_*), only columns < M are read and every code must be < K;
+ *       indices [n_tokens][nq] idx_dtype (RQAE_IDX_*), only columns < M are read; a code outside [0, K) contributes an
+ *       unspecified finite value (an LDS read, never a fault) and sets RQAE_STATUS_CODE_RANGE in *status (may be NULL);
  *       layers_dev [n_layers] int32 DEVICE array, each < M, any order, duplicates allowed;
  *       table must be 16-byte aligned and allocated in whole 16-byte pieces; out [n_tokens][n_layers] fp16.
  * Bit-equal to the reference (the level sum is a sequential fp32 chain per token; nothing is re-associated).
@@ -143,7 +154,7 @@ int rqae_hip_intensity_prepare(const void *codebook_sims, const int *center, con
                                void *table, void *wcum, void *stream);
 int rqae_hip_intensity(const void *table, const void *layer_weights, const void *wcum, int M, int K,
                        const void *indices, int idx_dtype, int64_t n_tokens, int nq, const int *layers_dev,
-                       int n_layers, void *out, void *stream);
+                       int n_layers, void *out, int32_t *status, void *stream);
 
 /*
  * The model's cached tables (rqae/model.py:133-178): what RQAEFeature and the demo server read
@@ -196,33 +207,35 @@ size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_share
 int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
                        const float *codebook, const float *w_out, const float *b_out, int codebook_shared, void *stream);
 size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels);
+/* Which kernels one rqae_hip_encode_gram call launches: per call, no process-wide state (NULL = the defaults, in
+ * parentheses; a negative field keeps its default).  Every combination computes the same function under the same parity
+ * policy; they differ in speed.
+ *   size        sizeof(rqae_hip_gram_options) (lets the struct grow)
+ *   fused       1: one persistent kernel (projection + level chain + reconstruction per 256-token tile)        (0)
+ *   proj        3: LDS-DMA projection kernel, 2: register-pipelined, 1: first form                               (3)
+ *   recon       2: token-stationary reconstruction with 512-byte store rows, 1: weights-stationary               (2)
+ *   lean_levels level chain of a single level group (levels <= 8): 2 = fp32 straight-through values handed to the
+ *               reconstruction kernel, 16 waves per workgroup; 1 = the same with 8 waves; 0 = the first form     (2)
+ *   pipe_chunk  > 0: passes of that many tokens, reconstruction of pass i on a second stream beside pass i+1    (0) */
+typedef struct rqae_hip_gram_options {
+    int32_t size;
+    int32_t fused, proj, recon, lean_levels;
+    int64_t pipe_chunk;
+} rqae_hip_gram_options;
 int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
-                         int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream);
+                         int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,
+                         const rqae_hip_gram_options *options, void *stream);
 /* RQAE.decode (rqae/model.py:250-252) on the matrix-core arm, every level of indices [n_tokens][levels] selected: the decode sum
  * as rqae_hip_encode_gram's reconstruction kernel computes it (bf16-piece products, fp32 accumulation: within 1e-6 relative of
  * rqae_hip_decode, not its bits), codebook rows gathered by the codes in the kernel.  HBM-write-bound: 9 216 + 8 levels bytes per
- * token at d = 2304.  Served for levels <= 8 (one level group); codes int64 / int32 / uint16, PRECONDITION 0 <= code < K. */
+ * token at d = 2304.  Served for levels <= 8 (one level group); codes int64 / int32 / uint16 checked as in rqae_hip_decode
+ * (-K <= code < K, else row 0 and RQAE_STATUS_CODE_RANGE in *status). */
 int rqae_hip_decode_gram_supported(int d, int c, int K, int L, int codebook_shared, int levels);
 int rqae_hip_decode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *indices, int idx_dtype,
-                         int64_t n_tokens, int levels, float *out, void *stream);
-/* Which kernels rqae_hip_encode_gram launches (defaults in parentheses; -1 leaves a setting as it is; the environment
- * variables RQAE_GRAM_FUSED / _PIPE / _PROJ / _RECON set the same at load).  Every combination computes the same function
- * under the same parity policy; they differ in speed.  Process-wide, not thread-safe against
- * concurrent encode calls: meant for benchmarks and tests.
- *   fused       1: one persistent kernel (projection + level chain + reconstruction per 256-token tile)        (0)
- *   pipe_chunk  > 0: passes of that many tokens, reconstruction of pass i on a second stream beside pass i+1    (0)
- *   proj        3: LDS-DMA projection kernel, 2: register-pipelined, 1: first form                               (3)
- *   recon       2: token-stationary reconstruction with 512-byte store rows, 1: weights-stationary               (2) */
-int rqae_hip_gram_configure(int fused, long long pipe_chunk, int proj, int recon);
-/* Level chain of a single level group (levels <= 8): lean = 2 (default; RQAE_GRAM_LEV2 at load) runs the form that hands
- * fp32 straight-through values to the reconstruction kernel, which splits them into bf16 pieces itself, with 16 waves per
- * workgroup (four per SIMD: one wave's serial part runs behind the others' scans; values and codes leave level by level to fit
- * 128 registers); 1 the same form with 8 waves; 0 the first form (bf16-piece operand rows written by the level chain); -1 keeps
- * the setting.  Same codes every way. */
-int rqae_hip_gram_configure_levels(int lean);
+                         int64_t n_tokens, int levels, float *out, int32_t *status, void *stream);
 int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x,
                                 int x_dtype, int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,
-                                void *stream, float *phase_ms);
+                                const rqae_hip_gram_options *options, void *stream, float *phase_ms);
 
 /* ---- Similarity search over a resident dataset of codes ------------------------------
  * Replaces the arithmetic of demo/server/server.py: get_intensities (:41-68) and IntensityEngine.find_examples
@@ -238,12 +251,14 @@ int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, 
  *                                table[l][codes[t][l]][q], rounded to fp16 per chunk of <= 64 levels, chunks added
  *                                in fp16 (server.py:214-252), and the range added to acc in fp16 (:257-260; first != 0
  *                                stores instead, as the reference's first range does).  codes [n_tokens][L] int32 or
- *                                uint16 (RQAE_IDX_*), device-resident; a code >= K reads zeros.
+ *                                uint16 (RQAE_IDX_*), device-resident; a code outside [0, K) contributes an unspecified finite
+ *                                value (an LDS read, never a fault) and sets RQAE_STATUS_CODE_RANGE in *status.
  *   rqae_hip_search_rank         max_out[q][r] fp16 / order_out[q][r] int32: per query position the sequences by
  *                                descending max over positions of acc (server.py:263-266); equal maxima in ascending
  *                                sequence order (torch.argsort there promises none).  Sequence n = tokens
  *                                [n S, (n + 1) S).  workspace: rqae_hip_search_rank_workspace_bytes(n_seqs, Q).
- *   rqae_hip_search_gather       out[q][e][s] fp16 = acc[examples[q * E + e]][s][q]  (server.py:293-311)
+ *   rqae_hip_search_gather       out[q][e][s] fp16 = acc[examples[q * E + e]][s][q]  (server.py:293-311); an example outside
+ *                                [0, n_seqs) yields zeros and sets RQAE_STATUS_CODE_RANGE in *status
  * Supported: Q <= 128, K <= 1280 (rqae_hip_search_supported).  All pointers are device pointers; acc and table_out
  * 16-byte aligned. */
 int rqae_hip_search_supported(int K, int Q);
@@ -251,12 +266,12 @@ size_t rqae_hip_search_table_bytes(int K, int n_levels);
 int rqae_hip_search_query_table(const void *sims16, int L, int K, const int32_t *query_codes, int Q, int64_t query_stride,
                                 int l0, int l1, void *table_out, void *stream);
 int rqae_hip_search_accumulate(const void *codes, int code_dtype, int64_t n_tokens, int L, const void *table, int K, int Q,
-                               int l0, int l1, void *acc, int first, void *stream);
+                               int l0, int l1, void *acc, int first, int32_t *status, void *stream);
 size_t rqae_hip_search_rank_workspace_bytes(int64_t n_seqs, int Q);
 int rqae_hip_search_rank(const void *acc, int64_t n_seqs, int S, int Q, void *max_out, int32_t *order_out, void *workspace,
                          size_t workspace_bytes, void *stream);
 int rqae_hip_search_gather(const void *acc, int64_t n_seqs, int S, int Q, const int32_t *examples, int E, void *out,
-                           void *stream);
+                           int32_t *status, void *stream);
 
 /* Human-readable name of the encode kernel variant chosen for a shape. */
 int rqae_hip_kernel_info(int d, int c, int K, int L, char *buf, size_t buflen);

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "librqae_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 IDX_I64, IDX_I32, IDX_U16 = 0, 1, 2
 
@@ -45,8 +45,6 @@ SYMBOLS = (
     "rqae_hip_gram_workspace_bytes",
     "rqae_hip_encode_gram",
     "rqae_hip_encode_gram_phases",
-    "rqae_hip_gram_configure",
-    "rqae_hip_gram_configure_levels",
     "rqae_hip_decode_gram_supported",
     "rqae_hip_decode_gram",
     "rqae_hip_search_supported",
@@ -63,6 +61,16 @@ _lib = None
 
 class NativeLibraryError(RuntimeError):
     pass
+
+
+class GramOptions(ctypes.Structure):
+    """include/rqae_hip.h: rqae_hip_gram_options -- which kernels ONE rqae_hip_encode_gram call launches (-1 = default)."""
+    _fields_ = [("size", ctypes.c_int32), ("fused", ctypes.c_int32), ("proj", ctypes.c_int32), ("recon", ctypes.c_int32),
+                ("lean_levels", ctypes.c_int32), ("pipe_chunk", ctypes.c_int64)]
+
+
+def gram_options(fused: int = -1, pipe_chunk: int = -1, proj: int = -1, recon: int = -1, lean_levels: int = -1) -> GramOptions:
+    return GramOptions(ctypes.sizeof(GramOptions), fused, proj, recon, lean_levels, pipe_chunk)
 
 
 def lib():
@@ -87,7 +95,7 @@ def lib():
     L.rqae_hip_encode.restype = i
     L.rqae_hip_quantize.argtypes = [vp, i64, i, i, vp, vp, vp, vp]
     L.rqae_hip_quantize.restype = i
-    L.rqae_hip_decode.argtypes = [vp, i, i, i, i, vp, i, i64, i, vp, vp, vp]
+    L.rqae_hip_decode.argtypes = [vp, i, i, i, i, vp, i, i64, i, vp, vp, vp, vp]
     L.rqae_hip_decode.restype = i
     L.rqae_hip_decode_values.argtypes = [vp, i, i, i, i, vp, i64, i, vp, vp, vp]
     L.rqae_hip_decode_values.restype = i
@@ -101,7 +109,7 @@ def lib():
     L.rqae_hip_gemma_denorm_patch.restype = i
     L.rqae_hip_intensity_prepare.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
     L.rqae_hip_intensity_prepare.restype = i
-    L.rqae_hip_intensity.argtypes = [vp, vp, vp, i, i, vp, i, i64, i, vp, i, vp, vp]
+    L.rqae_hip_intensity.argtypes = [vp, vp, vp, i, i, vp, i, i64, i, vp, i, vp, vp, vp]
     L.rqae_hip_intensity.restype = i
     L.rqae_hip_codebook_sims.argtypes = [vp, i, i, vp, vp]
     L.rqae_hip_codebook_sims.restype = i
@@ -121,17 +129,14 @@ def lib():
     L.rqae_hip_gram_pack.restype = i
     L.rqae_hip_gram_workspace_bytes.argtypes = [i, i, i, i, i64, i]
     L.rqae_hip_gram_workspace_bytes.restype = sz
-    L.rqae_hip_encode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, vp]
+    L.rqae_hip_encode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, ctypes.POINTER(GramOptions), vp]
     L.rqae_hip_encode_gram.restype = i
-    L.rqae_hip_encode_gram_phases.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.rqae_hip_encode_gram_phases.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, ctypes.POINTER(GramOptions), vp,
+                                              ctypes.POINTER(ctypes.c_float)]
     L.rqae_hip_encode_gram_phases.restype = i
-    L.rqae_hip_gram_configure.argtypes = [i, ctypes.c_longlong, i, i]
-    L.rqae_hip_gram_configure.restype = i
-    L.rqae_hip_gram_configure_levels.argtypes = [i]
-    L.rqae_hip_gram_configure_levels.restype = i
     L.rqae_hip_decode_gram_supported.argtypes = [i, i, i, i, i, i]
     L.rqae_hip_decode_gram_supported.restype = i
-    L.rqae_hip_decode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp]
+    L.rqae_hip_decode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp]
     L.rqae_hip_decode_gram.restype = i
     L.rqae_hip_search_supported.argtypes = [i, i]
     L.rqae_hip_search_supported.restype = i
@@ -139,13 +144,13 @@ def lib():
     L.rqae_hip_search_table_bytes.restype = sz
     L.rqae_hip_search_query_table.argtypes = [vp, i, i, vp, i, i64, i, i, vp, vp]
     L.rqae_hip_search_query_table.restype = i
-    L.rqae_hip_search_accumulate.argtypes = [vp, i, i64, i, vp, i, i, i, i, vp, i, vp]
+    L.rqae_hip_search_accumulate.argtypes = [vp, i, i64, i, vp, i, i, i, i, vp, i, vp, vp]
     L.rqae_hip_search_accumulate.restype = i
     L.rqae_hip_search_rank_workspace_bytes.argtypes = [i64, i]
     L.rqae_hip_search_rank_workspace_bytes.restype = sz
     L.rqae_hip_search_rank.argtypes = [vp, i64, i, i, vp, vp, vp, sz, vp]
     L.rqae_hip_search_rank.restype = i
-    L.rqae_hip_search_gather.argtypes = [vp, i64, i, i, vp, i, vp, vp]
+    L.rqae_hip_search_gather.argtypes = [vp, i64, i, i, vp, i, vp, vp, vp]
     L.rqae_hip_search_gather.restype = i
     if L.rqae_hip_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
@@ -253,7 +258,7 @@ def gram_workspace_bytes(dims, n_tokens: int, levels: int) -> int:
 
 
 def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels: int, want_recon: bool = True,
-                workspace: torch.Tensor | None = None):
+                workspace: torch.Tensor | None = None, options: GramOptions | None = None):
     """x2d [N,d] {f32,bf16,f16} -> (q_out [N,d] f32 | None, indices [N,levels] i64) on the matrix-core arm."""
     d, c, K, L_ = dims
     _require_cuda(x2d, "x")
@@ -272,7 +277,8 @@ def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels:
     with torch.cuda.device(x2d.device):
         rc = lib().rqae_hip_encode_gram(gpacked.data_ptr(), d, c, K, L_, int(bool(codebook_shared)), x2d.data_ptr(),
                                         _X_DTYPES[x2d.dtype], n, levels, q.data_ptr() if want_recon else None,
-                                        idx.data_ptr(), workspace.data_ptr(), _stream(x2d.device))
+                                        idx.data_ptr(), workspace.data_ptr(), ctypes.byref(options) if options is not None else None,
+                                        _stream(x2d.device))
     _check(rc, "rqae_hip_encode_gram")
     return q, idx
 
@@ -289,23 +295,18 @@ def decode_gram(gpacked, dims, codebook_shared: bool, idx2d: torch.Tensor) -> to
     if idx2d.dtype not in _IDX_DTYPES or idx2d.dim() != 2 or not idx2d.is_contiguous():
         raise RuntimeError("decode_gram: indices must be contiguous int64 / int32 / uint16 [N, levels]")
     n, levels = idx2d.shape
-    check_codes(idx2d, K, "decode", always=True)
     out = torch.empty((n, d), dtype=torch.float32, device=idx2d.device)
     if n:
         with torch.cuda.device(idx2d.device):
             rc = lib().rqae_hip_decode_gram(gpacked.data_ptr(), d, c, K, L_, int(bool(codebook_shared)), idx2d.data_ptr(),
-                                            _IDX_DTYPES[idx2d.dtype], n, levels, out.data_ptr(), _stream(idx2d.device))
+                                            _IDX_DTYPES[idx2d.dtype], n, levels, out.data_ptr(), _status_ptr(idx2d.device),
+                                            _stream(idx2d.device))
         _check(rc, "rqae_hip_decode_gram")
+        _codes_checked(idx2d.device, f"decode: index out of range for the codebook of {K} rows")
     return out
 
 
-def gram_configure(fused: int = -1, pipe_chunk: int = -1, proj: int = -1, recon: int = -1, lean_levels: int = -1):
-    """Select the kernels of the matrix-core arm (include/rqae_hip.h: rqae_hip_gram_configure[_levels]); -1 keeps a setting."""
-    _check(lib().rqae_hip_gram_configure(fused, pipe_chunk, proj, recon), "rqae_hip_gram_configure")
-    _check(lib().rqae_hip_gram_configure_levels(lean_levels), "rqae_hip_gram_configure_levels")
-
-
-def encode_gram_phases(gpacked, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True):
+def encode_gram_phases(gpacked, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True, options: GramOptions | None = None):
     """Measurement only: one encode_gram call timed per kernel -> [ms projection, ms level chain, ms reconstruction]."""
     d, c, K, L_ = dims
     n = x2d.shape[0]
@@ -316,7 +317,7 @@ def encode_gram_phases(gpacked, dims, x2d: torch.Tensor, levels: int, want_recon
     with torch.cuda.device(x2d.device):
         rc = lib().rqae_hip_encode_gram_phases(gpacked.data_ptr(), d, c, K, L_, 1, x2d.data_ptr(), _X_DTYPES[x2d.dtype], n,
                                                levels, q.data_ptr() if want_recon else None, idx.data_ptr(), ws.data_ptr(),
-                                               _stream(x2d.device), ms)
+                                               ctypes.byref(options) if options is not None else None, _stream(x2d.device), ms)
     _check(rc, "rqae_hip_encode_gram_phases")
     return [float(v) for v in ms]
 
@@ -345,28 +346,88 @@ def _mask_arg(level_mask):
     return buf, ctypes.cast(buf, ctypes.c_void_p)
 
 
-_CHECK_ALL_CODES = os.environ.get("RQAE_HIP_CHECK_CODES", "0") not in ("0", "")
+# ---- bad code indices: a status word instead of a device assertion (include/rqae_hip.h "Status word") -----------------------
+# The kernels that gather by caller-supplied codes never fault on a bad one: they read row 0 (or LDS) and OR a bit into a device
+# int32.  The reference raises a recoverable IndexError for such input (rqae/model.py:234, rqae/feature.py:120); so does this
+# wrapper, from the word.  RQAE_HIP_CHECK_CODES (or set_code_check()) selects when the word is read:
+#   "sync"  (default) after the call, with one stream synchronisation: IndexError is raised BY the call, as in the reference;
+#   "lazy"  the word is copied to pinned host memory behind the call (no synchronisation); a set bit raises IndexError at the
+#           next rqae_amd call that takes codes or at check_status() -- for loops that queue many calls;
+#   "off"   never read (the kernels still clamp).
+_CHECK_MODE = os.environ.get("RQAE_HIP_CHECK_CODES", "sync").lower()
+if _CHECK_MODE in ("1", "true", "on", ""):
+    _CHECK_MODE = "sync"
+if _CHECK_MODE in ("0", "false"):
+    _CHECK_MODE = "off"
+_status_words = {}     # device index -> (device int32[1], pinned host int32[1], [message of the last flagged-able call])
 
 
-def check_codes(idx: torch.Tensor, K: int, what: str, always: bool = True):
-    """Device-side assertion that every code is a codebook row (0 <= code < K).
+def set_code_check(mode: str):
+    """"sync" | "lazy" | "off" (see above)."""
+    global _CHECK_MODE
+    if mode not in ("sync", "lazy", "off"):
+        raise ValueError(f"code check mode {mode!r}")
+    _CHECK_MODE = mode
 
-    The kernels gather codebook / table rows by these values (include/rqae_hip.h states the precondition); the reference
-    raises IndexError for such input.  Two reductions and ``torch._assert_async``: no host synchronisation -- a violation
-    surfaces as a device-side assertion at the next synchronising call.  ``always=False`` (the multi-gigabyte code matrices
-    of ``intensity``) checks only small inputs unless RQAE_HIP_CHECK_CODES=1."""
-    if idx.numel() == 0 or not (always or _CHECK_ALL_CODES or idx.numel() <= (1 << 24)):
+
+def _status_entry(device):
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ent = _status_words.get(key)
+    if ent is None:
+        ent = (torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key)), torch.zeros(1, dtype=torch.int32).pin_memory(), [""])
+        _status_words[key] = ent
+    return ent
+
+
+def _status_ptr(device):
+    """Device pointer of this device's status word for a call that takes codes; in lazy mode a bit left by an EARLIER call
+    surfaces here, before the new call is queued."""
+    if _CHECK_MODE == "off":
+        return None
+    ent = _status_entry(device)
+    if _CHECK_MODE == "lazy" and int(ent[1][0]) != 0:
+        _raise_flagged(ent)
+    return ent[0].data_ptr()
+
+
+def _raise_flagged(ent):
+    msg = ent[2][0] or "code index out of range"
+    ent[0].zero_()
+    ent[1].zero_()
+    raise IndexError(f"rqae_amd: {msg}")
+
+
+def _codes_checked(device, message: str):
+    """Call after queuing a kernel that was handed the status word."""
+    if _CHECK_MODE == "off":
         return
-    if idx.dtype == torch.uint16:
-        if K >= 65536:
-            return
-        flat = idx.reshape(-1).view(torch.int16).to(torch.int32) & 0xFFFF if idx.numel() <= (1 << 24) else None
-        if flat is None:
-            return
-        hi, lo = flat.amax(), flat.amin()
+    ent = _status_entry(device)
+    ent[2][0] = message
+    if _CHECK_MODE == "sync":
+        if int(ent[0].item()) != 0:      # synchronises the stream
+            _raise_flagged(ent)
     else:
-        hi, lo = idx.amax(), idx.amin()
-    torch._assert_async((hi < K) & (lo >= 0), f"rqae_amd: {what}: code outside 0..{K - 1} (index out of range for the codebook)")
+        ent[1].copy_(ent[0], non_blocking=True)
+
+
+def check_status(device=None):
+    """Synchronise and raise IndexError if any call since the last check met a code outside its table (lazy mode's barrier)."""
+    ents = list(_status_words.values()) if device is None else [_status_entry(device)]
+    for ent in ents:
+        if int(ent[0].item()) != 0:
+            _raise_flagged(ent)
+
+
+def codes_in_range(idx: torch.Tensor, K: int, what: str, allow_negative: bool = False):
+    """Host-side range check of a SMALL code tensor (a query, a feature centre): raises IndexError as the reference's indexing
+    would.  One tiny reduction and a synchronisation -- not for dataset-sized inputs (those are checked by the kernels)."""
+    if idx.numel() == 0:
+        return
+    v = idx.to(torch.int64) if idx.dtype != torch.uint16 else (idx.view(torch.int16).to(torch.int64) & 0xFFFF)
+    lo = -K if allow_negative else 0
+    if bool(((v < lo) | (v >= K)).any()):
+        raise IndexError(f"rqae_amd: {what}: code outside {lo}..{K - 1} (index out of range for a table of {K} rows)")
 
 
 def decode(packed, dims, idx2d: torch.Tensor, level_mask=None) -> torch.Tensor:
@@ -379,12 +440,12 @@ def decode(packed, dims, idx2d: torch.Tensor, level_mask=None) -> torch.Tensor:
     out = torch.empty((n, d), dtype=torch.float32, device=idx2d.device)
     if n == 0:
         return out
-    check_codes(idx2d, K, "decode")
     keep, maskp = _mask_arg(level_mask)
     with torch.cuda.device(idx2d.device):
         rc = lib().rqae_hip_decode(packed.data_ptr(), d, c, K, L_, idx2d.data_ptr(), _IDX_DTYPES[idx2d.dtype],
-                                   n, nq, maskp, out.data_ptr(), _stream(idx2d.device))
+                                   n, nq, maskp, out.data_ptr(), _status_ptr(idx2d.device), _stream(idx2d.device))
     _check(rc, "rqae_hip_decode")
+    _codes_checked(idx2d.device, f"decode: index out of range for the codebook of {K} rows")
     return out
 
 
@@ -481,6 +542,7 @@ def intensity_prepare(codebook_sims: torch.Tensor, center: torch.Tensor, layer_w
     w = layer_weights[:M].to(device=dev, dtype=torch.float16).contiguous()
     if c.numel() != M or w.numel() != M:
         raise RuntimeError("intensity_prepare: center / layer_weights shorter than max(layers) + 1")
+    codes_in_range(c, K, "intensity: feature centre")      # rows of codebook_sims (rqae/feature.py:120 indexes by them)
     n16 = (M * K * 2 + 15) // 16
     table = torch.empty(n16 * 8, dtype=torch.float16, device=dev)   # whole 16-byte pieces
     wcum = torch.empty(M, dtype=torch.float16, device=dev)
@@ -499,13 +561,13 @@ def intensity(table, w, wcum, M: int, K: int, idx2d: torch.Tensor, layers_dev: t
     n, nq = idx2d.shape
     nl = layers_dev.numel()
     out = torch.empty((n, nl), dtype=torch.float16, device=idx2d.device)
-    check_codes(idx2d[:, :M] if nq > M else idx2d, K, "intensity", always=False)
     if n:
         with torch.cuda.device(idx2d.device):
             rc = lib().rqae_hip_intensity(table.data_ptr(), w.data_ptr(), wcum.data_ptr(), M, K, idx2d.data_ptr(),
                                           _IDX_DTYPES[idx2d.dtype], n, nq, layers_dev.data_ptr(), nl, out.data_ptr(),
-                                          _stream(idx2d.device))
+                                          _status_ptr(idx2d.device), _stream(idx2d.device))
         _check(rc, "rqae_hip_intensity")
+        _codes_checked(idx2d.device, f"intensity: token index out of range for the similarity table of {K} rows")
     return out
 
 
@@ -607,8 +669,9 @@ def search_accumulate(codes: torch.Tensor, table: torch.Tensor, K: int, Q: int, 
         raise RuntimeError("search_accumulate: acc must be contiguous float16 [N, S, 128] on the codes' device")
     with torch.cuda.device(codes.device):
         rc = lib().rqae_hip_search_accumulate(codes.data_ptr(), _IDX_DTYPES[codes.dtype], N * S, L_, table.data_ptr(), K, Q, l0, l1,
-                                              acc.data_ptr(), int(bool(first)), _stream(codes.device))
+                                              acc.data_ptr(), int(bool(first)), _status_ptr(codes.device), _stream(codes.device))
     _check(rc, "rqae_hip_search_accumulate")
+    _codes_checked(codes.device, f"search_accumulate: dataset code out of range for the table of {K} rows")
 
 
 def search_rank(acc: torch.Tensor, Q: int, workspace: torch.Tensor | None = None):
@@ -639,6 +702,8 @@ def search_gather(acc: torch.Tensor, Q: int, examples: torch.Tensor) -> torch.Te
     out = torch.empty((Q, E, S), dtype=torch.float16, device=acc.device)
     if E:
         with torch.cuda.device(acc.device):
-            rc = lib().rqae_hip_search_gather(acc.data_ptr(), N, S, Q, examples.data_ptr(), E, out.data_ptr(), _stream(acc.device))
+            rc = lib().rqae_hip_search_gather(acc.data_ptr(), N, S, Q, examples.data_ptr(), E, out.data_ptr(),
+                                              _status_ptr(acc.device), _stream(acc.device))
         _check(rc, "rqae_hip_search_gather")
+        _codes_checked(acc.device, f"search_gather: example outside the dataset of {N} sequences")
     return out

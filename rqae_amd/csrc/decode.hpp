@@ -130,6 +130,7 @@ struct DecParams {
     int d, dp, c, K, nlev, nq, idx_dtype;
     const float *rec_p;   // pass records (rqae_decode_lds_kernel reads the lin_out quads of record l+1)
     int aligned16;        // out 16-byte aligned: full tiles use vector stores
+    int *status;          // include/rqae_hip.h "Status word" (a code outside -K..K-1), or NULL
     uint32_t mask[MAX_MASK_LEVELS / 32];
 };
 
@@ -138,6 +139,18 @@ __device__ __forceinline__ long long load_idx(const void *src, int dt, size_t of
     if (dt == RQAE_IDX_I64) return reinterpret_cast<const long long *>(src)[off];
     if (dt == RQAE_IDX_I32) return reinterpret_cast<const int *>(src)[off];
     return reinterpret_cast<const uint16_t *>(src)[off];
+}
+
+// torch indexing as `self.codebook[0][indices]` applies it (rqae/model.py:234): -K <= code < K, a negative code counts from the
+// last row; anything else raises IndexError there -- here it reads row 0 and flags the call (never an out-of-bounds gather)
+__device__ __forceinline__ long long checked_code(long long ix, int K, int *status)
+{
+    ix = ix < 0 ? ix + K : ix;
+    if ((unsigned long long)ix >= (unsigned long long)K) {
+        if (status) atomicOr(status, RQAE_STATUS_CODE_RANGE);
+        ix = 0;
+    }
+    return ix;
 }
 
 // One workgroup = 4 waves (one per slice) x TPW tokens; the running sum stays in VGPRs,
@@ -173,7 +186,7 @@ rqae_decode_kernel(const DecParams p)
             if (!on || tok >= p.n_tokens) continue;
             const float *row;
             if constexpr (FROM_IDX) {
-                const long long ix = load_idx(p.src, p.idx_dtype, (size_t)tok * p.nq + l);
+                const long long ix = checked_code(load_idx(p.src, p.idx_dtype, (size_t)tok * p.nq + l), p.K, p.status);
                 row = p.cb0 + (size_t)ix * cp;  // level-0 codebook for every level (model.py:234)
             } else {
                 row = reinterpret_cast<const float *>(p.src) + ((size_t)tok * p.nq + l) * cp;
@@ -304,7 +317,7 @@ rqae_decode_lds_kernel(const DecParams p)
                 if (lv >= p.nlev || !level_on(lv) || tok >= p.n_tokens) continue;
                 const float *row;
                 if constexpr (FROM_IDX) {
-                    const long long ix = load_idx(p.src, p.idx_dtype, (size_t)tok * p.nq + lv);
+                    const long long ix = checked_code(load_idx(p.src, p.idx_dtype, (size_t)tok * p.nq + lv), p.K, p.status);
                     row = p.cb0 + (size_t)ix * C;             // level-0 codebook for every level (model.py:234)
                 } else {
                     row = reinterpret_cast<const float *>(p.src) + ((size_t)tok * p.nq + lv) * C;

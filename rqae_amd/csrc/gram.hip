@@ -1192,7 +1192,10 @@ __global__ __launch_bounds__(NW * 64) void gram_reconstruct_kernel(RecParams p)
 
 constexpr int B_NW = 8;
 
-// launch geometry knobs, read from the environment ONCE (first call), for measurements only
+// Kernel selection of one call.  The defaults are compiled in; a caller overrides them per call through
+// rqae_hip_gram_options (include/rqae_hip.h) -- there is no process-wide setting (re-entrant, no global mutable
+// state).  Tools builds (-DRQAE_GRAM_TOOLS: tools/ only) can also override the defaults from RQAE_GRAM_* environment
+// variables, read once.
 struct Tuning {
     int c_tt;            // reconstruct kernel: 16-token tiles per wave (2: 8 waves per workgroup, 1: 16 waves)
     long long chunk;     // tokens per pass
@@ -1205,33 +1208,52 @@ struct Tuning {
     int lev2;            // level chain of one level group: 2 = lean form (fp32 values to the reconstruction) with 16 waves per workgroup
                          // (default), 1 = lean form with 8 waves, 0 = first form
 };
-Tuning &tuning_mut()
+constexpr long long GRAM_CHUNK = 262144;   // tokens per pass: sizes the workspace (rqae_hip_gram_workspace_bytes), so not a per-call option
+
+Tuning default_tuning()
 {
-    static Tuning t = [] {
-        Tuning v;
-        v.chunk = 262144;
-        v.c_tt = 2;
-        v.proj = 3;
+    Tuning v;
+    v.chunk = GRAM_CHUNK;
+    v.c_tt = 2;
+    v.proj = 3;
+    v.recon = 2;
+    v.fused = 0;
+    v.pipe_chunk = 0;       // off: measured slower (profiles/r02_pipeline_trace.txt): the kernels are bound per CU, not by HBM
+    v.cap_ab = 160;
+    v.lev2 = 2;
+    v.stagger = 0;
+#ifdef RQAE_GRAM_TOOLS
+    static const Tuning env = [v]() mutable {
         if (const char *e = getenv("RQAE_GRAM_PROJ")) { const int a = atoi(e); v.proj = a >= 1 && a <= 3 ? a : 3; }
-        v.recon = 2;
         if (const char *e = getenv("RQAE_GRAM_RECON")) v.recon = atoi(e) == 1 ? 1 : 2;
-        v.fused = 0;
         if (const char *e = getenv("RQAE_GRAM_FUSED")) v.fused = atoi(e) != 0;
-        v.pipe_chunk = 0;       // off: measured slower (profiles/r02_pipeline_trace.txt): the kernels are bound per CU, not by HBM
         if (const char *e = getenv("RQAE_GRAM_PIPE")) { const long long c = atoll(e); v.pipe_chunk = c <= 0 ? 0 : ((c + 255) & ~255LL); }
-        v.cap_ab = 160;
         if (const char *e = getenv("RQAE_GRAM_CAP_AB")) { const int c = atoi(e); if (c >= 8) v.cap_ab = c; }
-        v.lev2 = 2;
         if (const char *e = getenv("RQAE_GRAM_LEV2")) { const int a = atoi(e); v.lev2 = a < 0 || a > 2 ? 1 : a; }
-        v.stagger = 0;
         if (const char *e = getenv("RQAE_GRAM_STAGGER")) v.stagger = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
-        if (const char *e = getenv("RQAE_GRAM_CHUNK")) { const long long c = atoll(e); if (c >= 64) v.chunk = (c + 63) & ~63LL; }
         return v;
     }();
-    return t;
+    return env;
+#else
+    return v;
+#endif
 }
-const Tuning &tuning() { return tuning_mut(); }
+
+// defaults overridden by the caller's options (a negative / zero-sized field keeps the default)
+int make_tuning(const rqae_hip_gram_options *o, Tuning &t)
+{
+    t = default_tuning();
+    if (!o) return 0;
+    if (o->size != (int32_t)sizeof(rqae_hip_gram_options)) return gfail("gram options: size %d, this library expects %d", (int)o->size, (int)sizeof(rqae_hip_gram_options));
+    if (o->fused >= 0) t.fused = o->fused != 0;
+    if (o->pipe_chunk >= 0) t.pipe_chunk = o->pipe_chunk == 0 ? 0 : ((o->pipe_chunk + 255) & ~255LL);
+    if (o->proj > 3 || o->recon > 2 || o->lean_levels > 2) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
+    if (o->proj >= 1) t.proj = o->proj;
+    if (o->recon >= 1) t.recon = o->recon;
+    if (o->lean_levels >= 0) t.lev2 = o->lean_levels;
+    return 0;
+}
 
 int device_cus()
 {
@@ -1270,7 +1292,7 @@ GView gview(const void *packed, int d, int c, int K, int L, int shared_cb)
     return v;
 }
 
-// tokens per pass (tuning().chunk, default 262144; measured: 65536 1.39 ms, 131072 1.15 ms, 262144 1.11 ms per 262144
+// tokens per pass (GRAM_CHUNK = 262144; measured: 65536 1.39 ms, 131072 1.15 ms, 262144 1.11 ms per 262144
 // tokens -- fewer launches beat cache residency of the intermediates)
 
 inline long long pad64(long long n) { return (n + 63) & ~63LL; }
@@ -1285,7 +1307,7 @@ size_t cv_row_bytes(const Geom &g, int levels)
 
 size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
 {
-    const long long ch = n_tokens < tuning().chunk ? n_tokens : tuning().chunk;
+    const long long ch = n_tokens < GRAM_CHUNK ? n_tokens : GRAM_CHUNK;
     const long long tp = pad64(ch);
     // projections, TWO operand-row buffers (the pipelined schedule reconstructs pass i while pass i+1 fills the other one), dump
     // rows, timeline stamps (tools build)
@@ -1406,8 +1428,12 @@ namespace {
 // ev: NULL, or 4 events recorded before the projection, between the kernels and after the reconstruction of the LAST
 // chunk (rqae_hip_encode_gram_phases)
 int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
-                     int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream, hipEvent_t *ev)
+                     int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, const rqae_hip_gram_options *opts,
+                     void *stream, hipEvent_t *ev)
 {
+    Tuning tun;
+    if (int rc = make_tuning(opts, tun)) return rc;
+    auto tuning = [&]() -> const Tuning & { return tun; };
     if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared)) return gfail("encode_gram: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
     if (!packed || !x || !indices || !workspace) return gfail("encode_gram: null pointer");
     if (levels < 1 || levels > L) return gfail("encode_gram: levels=%d outside 1..%d", levels, L);
@@ -1735,10 +1761,11 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
 extern "C" {
 
 int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
-                         int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream)
+                         int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,
+                         const rqae_hip_gram_options *options, void *stream)
 {
-    return encode_gram_impl(packed, d, c, K, L, codebook_shared, x, x_dtype, n_tokens, levels, q_out, indices, workspace, stream,
-                            nullptr);
+    return encode_gram_impl(packed, d, c, K, L, codebook_shared, x, x_dtype, n_tokens, levels, q_out, indices, workspace, options,
+                            stream, nullptr);
 }
 
 // RQAE.decode on the matrix-core arm: out = sum_l (W_out[l] codebook[idx_l] + b_out[l]) as the reconstruction kernel computes it
@@ -1751,7 +1778,7 @@ int rqae_hip_decode_gram_supported(int d, int c, int K, int L, int codebook_shar
 }
 
 int rqae_hip_decode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *indices, int idx_dtype,
-                         int64_t n_tokens, int levels, float *out, void *stream)
+                         int64_t n_tokens, int levels, float *out, int32_t *status, void *stream)
 {
 #ifdef RQAE_FUSED_QUICK
     return gfail("tools build: only the fused kernel is compiled in");
@@ -1768,7 +1795,7 @@ int rqae_hip_decode_gram(const void *packed, int d, int c, int K, int L, int cod
     const Geom &g = v.g;
     FusedParams pf;
     memset(&pf, 0, sizeof(pf));
-    pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = out; pf.cb_f32 = v.cb_f32; pf.codes = indices;
+    pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = out; pf.cb_f32 = v.cb_f32; pf.codes = indices; pf.status = status;
     pf.n_tokens = n_tokens; pf.tok_pad = pad64(n_tokens); pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c; pf.levels = levels; pf.L = L;
     pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET; pf.NKSC = g.NKSC; pf.stagger = 0; pf.nks_live = nks_recon(g, levels);
     long long nb = (n_tokens + F_TILE - 1) / F_TILE;
@@ -1789,30 +1816,14 @@ int rqae_hip_decode_gram(const void *packed, int d, int c, int K, int L, int cod
 #endif
 }
 
-int rqae_hip_gram_configure(int fused, long long pipe_chunk, int proj, int recon)
-{
-    Tuning &t = tuning_mut();
-    if (fused >= 0) t.fused = fused != 0;
-    if (pipe_chunk >= 0) t.pipe_chunk = pipe_chunk == 0 ? 0 : ((pipe_chunk + 255) & ~255LL);
-    if (proj >= 1 && proj <= 3) t.proj = proj;
-    if (recon >= 1 && recon <= 2) t.recon = recon;
-    return 0;
-}
-
-int rqae_hip_gram_configure_levels(int lean)
-{
-    if (lean >= 0) tuning_mut().lev2 = lean > 2 ? 2 : lean;
-    return 0;
-}
-
 int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
-                                int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, void *stream,
-                                float *phase_ms)
+                                int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,
+                                const rqae_hip_gram_options *options, void *stream, float *phase_ms)
 {
     if (!phase_ms) return gfail("encode_gram_phases: phase_ms is NULL");
     hipEvent_t ev[4];
     for (int i = 0; i < 4; ++i) G_TRY(hipEventCreate(&ev[i]));
-    int rc = encode_gram_impl(packed, d, c, K, L, codebook_shared, x, x_dtype, n_tokens, levels, q_out, indices, workspace, stream, ev);
+    int rc = encode_gram_impl(packed, d, c, K, L, codebook_shared, x, x_dtype, n_tokens, levels, q_out, indices, workspace, options, stream, ev);
     if (!rc && n_tokens > 0) {
         hipError_t e = hipEventSynchronize(ev[3]);
         if (e != hipSuccess) rc = gfail("encode_gram_phases: %s", hipGetErrorString(e));

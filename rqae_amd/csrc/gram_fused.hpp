@@ -48,6 +48,7 @@ struct FusedParams {
     int nks_live;              // MODE 2: k-steps the levels in use fill (the rest are zero)
     const float *cvf;          // MODE 3: fp32 straight-through values, level planes [8][tok_pad][CP]
     const void *codes;         // MODE 4: code indices [n_tokens][levels] (int64 / int32 / uint16 by the XT parameter: RQAE_IDX_*)
+    int *status;               // MODE 4: include/rqae_hip.h "Status word" (a code outside -K..K-1), or NULL
 };
 
 constexpr int F_NW = 8;                 // waves per workgroup
@@ -677,6 +678,13 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                         if constexpr (XT == RQAE_IDX_I64) code = static_cast<const long long *>(p.codes)[tok * levels + li];
                         else if constexpr (XT == RQAE_IDX_I32) code = static_cast<const int *>(p.codes)[tok * levels + li];
                         else code = static_cast<const unsigned short *>(p.codes)[tok * levels + li];
+                        // torch indexing (rqae/model.py:234): -K <= code < K; anything else raises IndexError there, here it reads
+                        // row 0 and flags the call (include/rqae_hip.h "Status word")
+                        code = code < 0 ? code + p.K : code;
+                        if ((unsigned long long)code >= (unsigned long long)p.K) {
+                            if (p.status) atomicOr(p.status, RQAE_STATUS_CODE_RANGE);
+                            code = 0;
+                        }
                     }
                     const float *row = p.cb_f32 + (size_t)code * c;
 #pragma unroll

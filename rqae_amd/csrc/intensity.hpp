@@ -1,5 +1,7 @@
 // intensity.hpp -- RQAEFeature.intensity: prepare and main kernels; included by rqae_hip.hip.
 #pragma once
+#include <type_traits>
+
 #include "rqae_common.hpp"
 
 namespace {
@@ -21,6 +23,7 @@ struct IntensityParams {
     _Float16 *out;            // [n_tokens][n_layers]
     long long n_tokens;
     int nq, M, K, LC, n_layers, vec_ok;
+    int *status;              // include/rqae_hip.h "Status word" (a code outside 0..K-1), or NULL
 };
 
 __global__ void intensity_prepare_kernel(const _Float16 *sims, const int *center, const _Float16 *w, int M, int K,
@@ -95,6 +98,11 @@ intensity_kernel(const IntensityParams p)
     load_tile(0, regs);
     load_table(0, tregs);
     float acc = 0.0f;
+    // largest code this lane met, as unsigned (a negative code is huge): the gathers below are LDS reads -- a code past the table
+    // reads other LDS bytes or, past the allocation, zeros, never a fault -- so the range check is one max per code and one
+    // compare at the end (the reference raises IndexError, rqae/feature.py:120)
+    typedef typename std::conditional<sizeof(IT) == 8, unsigned long long, unsigned>::type UT;
+    UT cmax = 0;
 
     for (int c0 = 0; c0 < p.M; c0 += p.LC) {
         const int m0 = c0 & ~(TL - 1);
@@ -149,7 +157,10 @@ intensity_kernel(const IntensityParams p)
             const ITV codes = tile[lane * RS + rel / EPC];
             float sv[EPC], wv[EPC];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) sv[e] = (float)tab[(m + e - c0) * p.K + (int)codes[e]];
+            for (int e = 0; e < EPC; ++e) {
+                cmax = cmax > (UT)codes[e] ? cmax : (UT)codes[e];
+                sv[e] = (float)tab[(m + e - c0) * p.K + (int)codes[e]];
+            }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) wv[e] = wf[rel + e];
 #pragma unroll
@@ -162,12 +173,14 @@ intensity_kernel(const IntensityParams p)
         for (; m < hi; ++m) {
             const int rel = m - m0;
             const IT code = reinterpret_cast<const IT *>(tile + lane * RS)[rel];
+            cmax = cmax > (UT)code ? cmax : (UT)code;
             const float sv = (float)tab[(m - c0) * p.K + (int)code];
             const _Float16 prod = (_Float16)(sv * wf[rel]);
             acc += (float)prod;
             if ((mask >> rel) & 1u) emit(m, rel);
         }
     }
+    if (tok < p.n_tokens && cmax >= (UT)p.K && p.status) atomicOr(p.status, RQAE_STATUS_CODE_RANGE);
 }
 
 }  // namespace

@@ -405,7 +405,7 @@ PackedView view_of(const void *packed, int d, int c, int K, int L)
 
 int decode_common(const void *packed, int d, int c, int K, int L, const void *src, bool from_idx,
                   int idx_dtype, int64_t n_tokens, int nq, const uint8_t *level_mask, float *out,
-                  void *stream)
+                  int *status, void *stream)
 {
     if (!shape_ok(d, c, K, L)) return fail("decode: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
     if (!packed || !src || !out) return fail("decode: null pointer");
@@ -430,6 +430,7 @@ int decode_common(const void *packed, int d, int c, int K, int L, const void *sr
     p.src = src; p.out = out; p.n_tokens = n_tokens;
     p.d = d; p.dp = v.dp; p.c = c; p.K = K; p.nlev = top; p.nq = nq; p.idx_dtype = idx_dtype;
     p.aligned16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    p.status = status;
     return dispatch_decode(v.dp / 256, c, p, from_idx, static_cast<hipStream_t>(stream));
 }
 
@@ -594,15 +595,15 @@ int rqae_hip_quantize(const float *pin, int64_t n, int c, int K, const float *co
 }
 
 int rqae_hip_decode(const void *packed, int d, int c, int K, int L, const void *indices, int idx_dtype,
-                    int64_t n_tokens, int idx_levels, const uint8_t *level_mask, float *out, void *stream)
+                    int64_t n_tokens, int idx_levels, const uint8_t *level_mask, float *out, int32_t *status, void *stream)
 {
-    return decode_common(packed, d, c, K, L, indices, true, idx_dtype, n_tokens, idx_levels, level_mask, out, stream);
+    return decode_common(packed, d, c, K, L, indices, true, idx_dtype, n_tokens, idx_levels, level_mask, out, status, stream);
 }
 
 int rqae_hip_decode_values(const void *packed, int d, int c, int K, int L, const float *cv, int64_t n_tokens,
                            int nq, const uint8_t *level_mask, float *out, void *stream)
 {
-    return decode_common(packed, d, c, K, L, cv, false, 0, n_tokens, nq, level_mask, out, stream);
+    return decode_common(packed, d, c, K, L, cv, false, 0, n_tokens, nq, level_mask, out, nullptr, stream);
 }
 
 int rqae_hip_gemma_norm(const void *hs, int hs_dtype, const float *norm_weight, float eps, int64_t n_tokens, int d,
@@ -691,7 +692,7 @@ int rqae_hip_intensity_prepare(const void *codebook_sims, const int *center, con
 
 int rqae_hip_intensity(const void *table, const void *layer_weights, const void *wcum, int M, int K,
                        const void *indices, int idx_dtype, int64_t n_tokens, int nq, const int *layers_dev,
-                       int n_layers, void *out, void *stream)
+                       int n_layers, void *out, int32_t *status, void *stream)
 {
     if (!table || !layer_weights || !wcum || !indices || !layers_dev || !out) return fail("intensity: null pointer");
     if (M < 1 || K < 1 || nq < M || n_layers < 1) return fail("intensity: bad sizes M=%d K=%d nq=%d n_layers=%d", M, K, nq, n_layers);
@@ -701,7 +702,7 @@ int rqae_hip_intensity(const void *table, const void *layer_weights, const void 
     IntensityParams p;
     p.table = (const _Float16 *)table; p.w = (const _Float16 *)layer_weights; p.wcum = (const _Float16 *)wcum;
     p.idx = indices; p.layers = layers_dev; p.out = (_Float16 *)out;
-    p.n_tokens = n_tokens; p.nq = nq; p.M = M; p.K = K; p.n_layers = n_layers;
+    p.n_tokens = n_tokens; p.nq = nq; p.M = M; p.K = K; p.n_layers = n_layers; p.status = status;
     const size_t es = idx_dtype == RQAE_IDX_I64 ? 8 : idx_dtype == RQAE_IDX_I32 ? 4 : 2;
     const int TL = 16;
     int LC = TL;

@@ -16,8 +16,10 @@
 //     gathers 16 bytes (8 query positions) of its token's row with one ds_read_b128 and adds them into fp32 registers
 //     (v_fma_mix_f32: fp16 in, fp32 accumulate); 64-level chunks fold to fp16 exactly as the reference's chunked sums do; the
 //     running fp16 accumulation [N][S][128] is read and written once per level range;
-//   * search_rowmax_kernel + rocPRIM's segmented radix sort (stable: equal maxima keep ascending sequence order) rank the
-//     sequences; search_gather_kernel fetches the chosen examples' rows.
+//   * search_rowmax_kernel + a hand-written bitonic sort in LDS (search_sort_kernel: one workgroup per query position and
+//     chunk of 8192 sequences, 64-bit keys (descending maximum, ascending sequence number) -- so equal maxima keep ascending
+//     sequence order; longer datasets merge chunks through global memory) rank the sequences; search_gather_kernel fetches the
+//     chosen examples' rows.
 //
 // Arithmetic (oracle/search_oracle.py restates it; tests/golden/search.npz is the reference's own output): per (n, s, q) and
 // chunk of <= 64 levels an fp32 sum in ascending level order, rounded once to fp16; fp16 additions of chunks and of ranges.
@@ -30,8 +32,6 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
-
-#include <hipcub/hipcub.hpp>
 
 #include "../../include/rqae_hip.h"
 
@@ -117,6 +117,8 @@ struct AccParams {
     __half *acc;             // [NT][128]
     long long NT;
     int Ltot, KP, l0, l1, first, nbuf, dbg;
+    int K;                   // rows of the table that exist (codes >= K are flagged)
+    int *status;             // include/rqae_hip.h "Status word", or NULL
 };
 
 template <typename CT> struct CodeBlock;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(S_NW * 64) void search_accumulate_kernel(AccParams 
 
     float acc[S_TS][8];
     h16x2 rng[S_TS][4];
+    unsigned cmax = 0u;      // largest code this lane fetched (as unsigned: a negative int32 code is huge), checked once at the end
 #pragma unroll
     for (int ts = 0; ts < S_TS; ++ts)
 #pragma unroll
@@ -241,13 +244,14 @@ __global__ __launch_bounds__(S_NW * 64) void search_accumulate_kernel(AccParams 
                 for (int ts = 0; ts < S_TS; ++ts) {
                     unsigned w;
                     const unsigned mine = CB::code(cw[ts >> 2], j);
+                    if ((ts & 3) == 0) cmax = cmax > mine ? cmax : mine;       // each lane's own codes once (NSET per level)
                     switch (ts & 3) {
                     case 0: w = quad_bcast<0>(mine); break;
                     case 1: w = quad_bcast<1>(mine); break;
                     case 2: w = quad_bcast<2>(mine); break;
                     default: w = quad_bcast<3>(mine); break;
                     }
-                    row[ts] = *reinterpret_cast<const u32x4 *>(base + (size_t)w * 64);     // past the slice: LDS returns zeros past its end
+                    row[ts] = *reinterpret_cast<const u32x4 *>(base + (size_t)w * 64);     // a code past the slice reads other LDS bytes or, past the allocation, zeros: never a fault (flagged below)
                 }
 #pragma unroll
                 for (int ts = 0; ts < S_TS; ++ts)
@@ -279,6 +283,9 @@ __global__ __launch_bounds__(S_NW * 64) void search_accumulate_kernel(AccParams 
 #pragma unroll
             for (int i = 0; i < NDW; ++i) cw[st][i] = cwn[st][i];
     }
+    // a code outside the table: the reference raises IndexError (server.py:55); here the call is flagged (lanes of rows past the
+    // dataset re-read its last row, so they add nothing new)
+    if (cmax >= (unsigned)p.K && p.status) atomicOr(p.status, RQAE_STATUS_CODE_RANGE);
     // ---- the running accumulation over ranges (server.py:257-260)
 #pragma unroll
     for (int ts = 0; ts < S_TS; ++ts) {
@@ -297,12 +304,12 @@ __global__ __launch_bounds__(S_NW * 64) void search_accumulate_kernel(AccParams 
 }
 
 // ------------------------------------------------------------------------------------------------ ranking
-// keys[q][n] = max over s of acc[n][s][q] (server.py:263), vals[q][n] = n.  One workgroup per sequence: thread (row group
+// keys[q][n] = max over s of acc[n][s][q] (server.py:263).  One workgroup per sequence: thread (row group
 // tid >> 4, column block tid & 15) runs over every 16th position with 16-byte loads (8 query positions), then the 16 row
 // groups meet in LDS.  A NaN takes the maximum and keeps it, like torch.max.
 __device__ __forceinline__ float max_nan(float m, float v) { return (v > m || (v != v && m == m)) ? v : m; }
 
-__global__ __launch_bounds__(256) void search_rowmax_kernel(const __half *acc, long long N, int S, int Q, __half *keys, int *vals)
+__global__ __launch_bounds__(256) void search_rowmax_kernel(const __half *acc, long long N, int S, int Q, __half *keys)
 {
     __shared__ float part[16][S_QP + 4];
     const long long n = blockIdx.x;
@@ -324,25 +331,103 @@ __global__ __launch_bounds__(256) void search_rowmax_kernel(const __half *acc, l
         float r = part[0][q];
         for (int i = 1; i < 16; ++i) r = max_nan(r, part[i][q]);
         if (q < Q) {
-            r = r == 0.0f ? 0.0f : r;                            // -0 ranks with +0 (the radix sort would put it below)
+            r = r == 0.0f ? 0.0f : r;                            // -0 ranks with +0 (their bit patterns would order them)
             keys[(size_t)q * N + n] = __float2half(r);          // exact: r is one of the fp16 inputs (or -inf for S < 1, excluded by the host)
-            vals[(size_t)q * N + n] = (int)n;
         }
     }
 }
 
-struct SegOffset {
-    long long n;
-    __host__ __device__ int operator()(int q) const { return (int)((long long)q * n); }
-};
+// ---- ranking: per query position the sequences by descending maximum, equal maxima in ascending sequence order
+// (server.py:262-266 argsorts the maxima; torch promises no order among equals, this one is the stable order).
+// Sort key of sequence n: ((0xFFFF - m16(max)) << 32) | n, ascending, with m16 the usual order-preserving map of fp16 bits to
+// unsigned (NaN on top, as torch.sort places it).  A bitonic network: search_sort_kernel sorts chunks of up to SORT_CH keys in
+// LDS (and finishes every later stage's strides below the chunk length there), search_merge_kernel does the strides that cross
+// chunks in global memory.  Pad keys are all ones: they end up behind every sequence.
+constexpr int SORT_CH = 8192;            // keys per chunk: 64 KiB of LDS
+constexpr int SORT_NT = 1024;            // threads per workgroup
 
-// out[q][e][s] = acc[idx[q][e]][s][q]  (server.py:293-311)
-__global__ __launch_bounds__(128) void search_gather_kernel(const __half *acc, long long N, int S, const int *idx, int E, __half *out)
+__device__ __forceinline__ unsigned long long sort_key(__half v, unsigned n)
+{
+    const unsigned u = __half_as_ushort(v);
+    unsigned m = (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+    if ((u & 0x7fffu) > 0x7c00u) m = 0xffffu;                       // NaN of either sign: the maximum
+    return ((unsigned long long)(0xffffu - m) << 32) | n;
+}
+
+// keys64 [Q][NP] (NP = padded sequence count, a power of two >= ch).  MODE 0: build the keys from the maxima and sort every
+// chunk of `ch` (stages k = 2 .. ch); MODE 1: stage `kstage` > ch, strides ch/2 .. 1.  last != 0: this launch completes the
+// sort -- the first N keys of the row leave as (order, max) instead of going back to keys64.
+template <int MODE>
+__global__ __launch_bounds__(SORT_NT) void search_sort_kernel(const __half *maxima, unsigned long long *keys64, long long N, long long NP,
+                                                               int ch, long long kstage, int last, __half *max_out, int *order_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+    const int q = blockIdx.y;
+    const long long base = (long long)blockIdx.x * ch;
+    unsigned long long *row = keys64 + (size_t)q * NP;
+    for (int i = threadIdx.x; i < ch; i += SORT_NT) {
+        const long long n = base + i;
+        if (MODE == 0) sk[i] = n < N ? sort_key(maxima[(size_t)q * N + n], (unsigned)n) : ~0ull;
+        else sk[i] = row[n];
+    }
+    __syncthreads();
+    auto strides = [&](long long k, int jfirst) {
+        for (int j = jfirst; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < ch / 2; t += SORT_NT) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool up = ((base + lo) & k) == 0;             // ascending block of this stage
+                const unsigned long long a = sk[lo], b = sk[hi];
+                if ((a > b) == up) { sk[lo] = b; sk[hi] = a; }
+            }
+            __syncthreads();
+        }
+    };
+    if (MODE == 0) {
+        for (int k = 2; k <= ch; k <<= 1) strides(k, k >> 1);
+    } else {
+        strides(kstage, ch >> 1);
+    }
+    for (int i = threadIdx.x; i < ch; i += SORT_NT) {
+        const long long r = base + i;
+        if (!last) {
+            row[r] = sk[i];
+        } else if (r < N) {
+            const unsigned n = (unsigned)(sk[i] & 0xffffffffull);      // ranks < N hold sequences: the pads sort behind them
+            order_out[(size_t)q * N + r] = (int)n;
+            max_out[(size_t)q * N + r] = maxima[(size_t)q * N + n];
+        }
+    }
+}
+
+// one stride j >= ch of stage k, in global memory
+__global__ __launch_bounds__(256) void search_merge_kernel(unsigned long long *keys64, long long NP, long long k, long long j)
+{
+    unsigned long long *row = keys64 + (size_t)blockIdx.y * NP;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= NP / 2) return;
+    const long long lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+    const bool up = (lo & k) == 0;
+    const unsigned long long a = row[lo], b = row[hi];
+    if ((a > b) == up) { row[lo] = b; row[hi] = a; }
+}
+
+inline long long sort_pad(long long n)
+{
+    long long p = 2;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// out[q][e][s] = acc[idx[q][e]][s][q]  (server.py:293-311); an example outside the dataset (the reference raises IndexError)
+// yields zeros and flags the call
+__global__ __launch_bounds__(128) void search_gather_kernel(const __half *acc, long long N, int S, const int *idx, int E, __half *out, int *status)
 {
     const int q = blockIdx.x, e = blockIdx.y;
-    long long n = idx[(size_t)q * E + e];
-    n = n < 0 ? 0 : (n >= N ? N - 1 : n);
-    for (int s = threadIdx.x; s < S; s += blockDim.x) out[((size_t)q * E + e) * S + s] = acc[((size_t)n * S + s) * S_QP + q];
+    const long long n = idx[(size_t)q * E + e];
+    const bool ok = n >= 0 && n < N;
+    if (!ok && status && threadIdx.x == 0) atomicOr(status, RQAE_STATUS_CODE_RANGE);
+    for (int s = threadIdx.x; s < S; s += blockDim.x)
+        out[((size_t)q * E + e) * S + s] = ok ? acc[((size_t)n * S + s) * S_QP + q] : __float2half(0.0f);
 }
 
 int pick_nbuf(int KP)
@@ -380,7 +465,7 @@ int rqae_hip_search_query_table(const void *sims16, int L, int K, const int32_t 
 }
 
 int rqae_hip_search_accumulate(const void *codes, int code_dtype, int64_t n_tokens, int L, const void *table, int K, int Q, int l0,
-                               int l1, void *acc, int first, void *stream)
+                               int l1, void *acc, int first, int32_t *status, void *stream)
 {
     if (!codes || !table || !acc) return sfail("search_accumulate: null pointer");
     if (!rqae_hip_search_supported(K, Q)) return sfail("search_accumulate: unsupported K=%d Q=%d (Q <= 128, K <= 1280)", K, Q);
@@ -392,6 +477,7 @@ int rqae_hip_search_accumulate(const void *codes, int code_dtype, int64_t n_toke
     AccParams p;
     p.codes = codes; p.tq = static_cast<const __half *>(table); p.acc = static_cast<__half *>(acc); p.NT = n_tokens; p.Ltot = L;
     p.KP = ((K + 15) / 16) * 16; p.l0 = l0; p.l1 = l1; p.first = first ? 1 : 0; p.nbuf = pick_nbuf(p.KP);
+    p.K = K; p.status = status;
     p.dbg = 0;
 #ifdef RQAE_SEARCH_TOOLS   /* tools build: ring depth and the no-refill ablation (profiles/r02_search_ring_and_dma_ablation.txt) */
     static const int dbg = getenv("RQAE_SEARCH_DBG") ? atoi(getenv("RQAE_SEARCH_DBG")) : 0;
@@ -414,16 +500,9 @@ int rqae_hip_search_accumulate(const void *codes, int code_dtype, int64_t n_toke
 size_t rqae_hip_search_rank_workspace_bytes(int64_t n_seqs, int Q)
 {
     if (n_seqs < 1 || Q < 1 || Q > S_QP || n_seqs * Q > 0x7fffffffLL) return 0;
-    const int items = (int)(n_seqs * Q);
-    size_t tmp = 0;
-    hipcub::CountingInputIterator<int> cnt(0);
-    hipcub::TransformInputIterator<int, SegOffset, hipcub::CountingInputIterator<int>> begins(cnt, SegOffset{n_seqs});
-    if (hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, tmp, static_cast<const __half *>(nullptr), static_cast<__half *>(nullptr),
-                                                              static_cast<const int *>(nullptr), static_cast<int *>(nullptr), items, Q, begins,
-                                                              begins + 1, 0, 16, nullptr) != hipSuccess)
-        return 0;
-    const size_t keys = ((size_t)items * 2 + 255) & ~(size_t)255, vals = ((size_t)items * 4 + 255) & ~(size_t)255;
-    return keys + vals + ((tmp + 255) & ~(size_t)255) + 256;
+    // the maxima [Q][N] fp16 and the 64-bit sort keys [Q][NP]
+    const size_t maxima = ((size_t)n_seqs * Q * 2 + 255) & ~(size_t)255;
+    return maxima + (size_t)Q * sort_pad(n_seqs) * 8 + 256;
 }
 
 int rqae_hip_search_rank(const void *acc, int64_t n_seqs, int S, int Q, void *max_out, int32_t *order_out, void *workspace,
@@ -433,31 +512,46 @@ int rqae_hip_search_rank(const void *acc, int64_t n_seqs, int S, int Q, void *ma
     if (n_seqs < 1 || S < 1 || Q < 1 || Q > S_QP || n_seqs * Q > 0x7fffffffLL) return sfail("search_rank: bad shape");
     const size_t need = rqae_hip_search_rank_workspace_bytes(n_seqs, Q);
     if (!need || workspace_bytes < need) return sfail("search_rank: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+    if (reinterpret_cast<uintptr_t>(workspace) & 7) return sfail("search_rank: workspace must be 8-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int items = (int)(n_seqs * Q);
-    const size_t keys_b = ((size_t)items * 2 + 255) & ~(size_t)255, vals_b = ((size_t)items * 4 + 255) & ~(size_t)255;
+    const size_t maxima_b = ((size_t)n_seqs * Q * 2 + 255) & ~(size_t)255;
     char *w = static_cast<char *>(workspace);
-    __half *keys = reinterpret_cast<__half *>(w);
-    int *vals = reinterpret_cast<int *>(w + keys_b);
-    void *tmp = w + keys_b + vals_b;
-    size_t tmp_bytes = need - keys_b - vals_b;
+    __half *maxima = reinterpret_cast<__half *>(w);
+    unsigned long long *keys64 = reinterpret_cast<unsigned long long *>(w + maxima_b);
     hipLaunchKernelGGL(search_rowmax_kernel, dim3((unsigned)n_seqs), dim3(256), 0, s, static_cast<const __half *>(acc), (long long)n_seqs, S, Q,
-                       keys, vals);
+                       maxima);
     S_TRY(hipGetLastError());
-    hipcub::CountingInputIterator<int> cnt(0);
-    hipcub::TransformInputIterator<int, SegOffset, hipcub::CountingInputIterator<int>> begins(cnt, SegOffset{n_seqs});
-    S_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(tmp, tmp_bytes, keys, static_cast<__half *>(max_out), vals, order_out, items, Q,
-                                                                begins, begins + 1, 0, 16, s));
+    const long long NP = sort_pad(n_seqs);
+    const int ch = NP < SORT_CH ? (int)NP : SORT_CH;
+    const size_t lds = (size_t)ch * 8;
+    const dim3 grid((unsigned)(NP / ch), (unsigned)Q);
+    if (lds > 48 * 1024) {
+        S_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(search_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        S_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(search_sort_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(search_sort_kernel<0>, grid, dim3(SORT_NT), lds, s, maxima, keys64, (long long)n_seqs, NP, ch, 0LL, NP == ch ? 1 : 0,
+                       static_cast<__half *>(max_out), order_out);
+    S_TRY(hipGetLastError());
+    for (long long k = 2LL * ch; k <= NP; k <<= 1) {
+        for (long long j = k >> 1; j >= ch; j >>= 1) {
+            hipLaunchKernelGGL(search_merge_kernel, dim3((unsigned)((NP / 2 + 255) / 256), (unsigned)Q), dim3(256), 0, s, keys64, NP, k, j);
+            S_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(search_sort_kernel<1>, grid, dim3(SORT_NT), lds, s, maxima, keys64, (long long)n_seqs, NP, ch, k, k == NP ? 1 : 0,
+                           static_cast<__half *>(max_out), order_out);
+        S_TRY(hipGetLastError());
+    }
     return 0;
 }
 
-int rqae_hip_search_gather(const void *acc, int64_t n_seqs, int S, int Q, const int32_t *examples, int E, void *out, void *stream)
+int rqae_hip_search_gather(const void *acc, int64_t n_seqs, int S, int Q, const int32_t *examples, int E, void *out, int32_t *status,
+                           void *stream)
 {
     if (!acc || !examples || !out) return sfail("search_gather: null pointer");
     if (n_seqs < 1 || S < 1 || Q < 1 || Q > S_QP || E < 0) return sfail("search_gather: bad shape");
     if (E == 0) return 0;
     hipLaunchKernelGGL(search_gather_kernel, dim3((unsigned)Q, (unsigned)E), dim3(128), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const __half *>(acc), (long long)n_seqs, S, examples, E, static_cast<__half *>(out));
+                       static_cast<const __half *>(acc), (long long)n_seqs, S, examples, E, static_cast<__half *>(out), status);
     S_TRY(hipGetLastError());
     return 0;
 }

@@ -79,6 +79,7 @@ class RQAE(nn.Module):
         self._packed_key = None
         self._gram = None            # (key, packed block, shared flag) of the matrix-core arm
         self._gram_ws = None
+        self.gram_options = None     # _native.gram_options(...): kernel selection of this module's matrix-core calls (None = defaults)
         # which encode arm forward()/encode() take (not a reference argument; rides in **kwargs so the reference's
         # constructor signature stays as it is):
         #   "exact" (default) -- rqae_hip_encode: the canonical fp32 order, bit-equal to the CPU oracle
@@ -149,6 +150,7 @@ class RQAE(nn.Module):
         state["_packed_key"] = None
         state["_gram"] = None
         state["_gram_ws"] = None
+        state["gram_options"] = None      # a ctypes struct: not picklable, and a per-process tuning choice anyway
         state.pop("_param_list", None)
         return state
 
@@ -269,7 +271,7 @@ class RQAE(nn.Module):
         if ws is None or ws.device != x2d.device or ws.numel() < need:
             ws = self._gram_ws = torch.empty(need, dtype=torch.uint8, device=x2d.device)
         return _native.encode_gram(self.gram_packed_weights(), self._dims(), True, x2d, levels,
-                                   want_recon=want_recon, workspace=ws)
+                                   want_recon=want_recon, workspace=ws, options=self.__dict__.get("gram_options"))
 
     # ------------------------------------------------------------- small mirrors
     def update_codebook_counts(self, indices):

@@ -55,18 +55,21 @@ class IntensityEngine:
             if s.dim() != 3 or s.shape[1:] != shards[0].shape[1:]:
                 raise ValueError("every shard must be [n, S, num_quantizers]")
             s = s.to(device)
-            _native.check_codes(s, K, "IntensityEngine activations", always=False)
-            s = s.to(torch.int32)
+            if code_dtype == torch.uint16 and s.dtype != torch.uint16:
+                # the wrap-around cast below keeps the low 16 bits: anything it would fold into range is rejected here, once, at
+                # load (the accumulate kernel flags what is left: codes in K..65535)
+                if bool(((s < 0) | (s > 65535)).any()):
+                    raise IndexError(f"IntensityEngine: dataset code outside 0..{K - 1}")
+            s = s.to(torch.int32) if s.dtype != torch.uint16 else s
             # int32 -> uint16 by way of int16 (the wrap-around cast keeps the low 16 bits)
-            parts.append(s.to(torch.int16).view(torch.uint16) if code_dtype == torch.uint16 else s)
+            if code_dtype == torch.uint16 and s.dtype != torch.uint16:
+                s = s.to(torch.int16).view(torch.uint16)
+            parts.append(s)
         self.activations = torch.cat(parts, dim=0).contiguous()          # [N, S, L]
         self.shard_size = shard_size
         self.device = device
         self.K = K
-        N, S, _ = self.activations.shape
-        self._acc = torch.empty((N, S, QP), dtype=torch.float16, device=device)
-        self._rank_ws = None
-        self._table = None
+        self._acc = None          # the accumulation of the most recent find_examples step (accumulated())
 
     @property
     def num_sequences(self) -> int:
@@ -92,7 +95,11 @@ class IntensityEngine:
     def find_examples(self, idx: Optional[int] = None, activation: Optional[torch.Tensor] = None, top_examples: int = 30,
                       middle_examples: int = 10, bottom_examples: int = 10, layers: Sequence[int] = tuple(DEFAULT_LAYERS)):
         """Generator, one item per entry of ``layers`` (server.py:160-325): ``({"top"|"middle"|"bottom": {"indices":
-        int32 [Q, E], "intensities": fp16 [Q, E, S]}}, layer)`` on the CPU, like the reference's ``.cpu()`` results."""
+        int32 [Q, E], "intensities": fp16 [Q, E, S]}}, layer)`` on the CPU, like the reference's ``.cpu()`` results.
+
+        The running accumulation, the range's table and the ranking workspace belong to THIS call (the reference keeps
+        ``intensity_accumulation`` per call too, :206): several live generators of one engine -- the server streams them
+        through ``find_examples.remote_gen`` -- do not disturb one another.  33 MB per 1024-sequence shard and call."""
         layers = [int(v) for v in layers]
         if not layers or any(b <= a for a, b in zip([0] + layers[:-1], layers)):
             raise ValueError("layers must be increasing and positive")
@@ -105,20 +112,28 @@ class IntensityEngine:
             raise ValueError("the query has fewer levels than max(layers)")
         if not _native.search_supported(self.K, Q):
             raise RuntimeError(f"find_examples: K={self.K}, Q={Q} not served (Q <= 128, K <= 1280)")
-        _native.check_codes(query, self.K, "find_examples query", always=True)
+        _native.codes_in_range(query, self.K, "find_examples query")    # server.py:195-198 indexes the table by these: IndexError there
         bounds = [0] + layers
+        acc = torch.empty((N, S, QP), dtype=torch.float16, device=self.device)
+        table = rank_ws = None
         for step, (layer, l0, l1) in enumerate(zip(layers, bounds[:-1], bounds[1:])):
-            self._table = _native.search_query_table(self.sims, query, l0, l1, self._table)
-            _native.search_accumulate(self.activations, self._table, self.K, Q, l0, l1, self._acc, first=(step == 0))
-            _, order, self._rank_ws = _native.search_rank(self._acc, Q, self._rank_ws)
+            table = _native.search_query_table(self.sims, query, l0, l1, table)
+            _native.search_accumulate(self.activations, table, self.K, Q, l0, l1, acc, first=(step == 0))
+            _, order, rank_ws = _native.search_rank(acc, Q, rank_ws)
+            # the reference's slices of the ranking, as written there (server.py:268-280): `[-bottom_examples:]` with
+            # bottom_examples = 0 is the WHOLE ranking, and a middle window past the ends is clipped by the slice
             mid0, mid1 = N // 2 - middle_examples // 2, N // 2 + middle_examples // 2
-            picks = {"top": order[:, :top_examples], "middle": order[:, mid0:mid1], "bottom": order[:, N - bottom_examples:]}
+            picks = {"top": order[:, :top_examples], "middle": order[:, mid0:mid1], "bottom": order[:, -bottom_examples:]}
             out = {}
             for name, ex in picks.items():
                 ex = ex.contiguous()
-                out[name] = {"indices": ex.cpu().int(), "intensities": _native.search_gather(self._acc, Q, ex).cpu()}
+                out[name] = {"indices": ex.cpu().int(), "intensities": _native.search_gather(acc, Q, ex).cpu()}
+            self._acc = acc
             yield out, layer
 
     def accumulated(self, Q: int) -> torch.Tensor:
-        """The running fp16 accumulation ``[N, S, Q]`` after the last yielded layer (the reference's ``intensity_accumulation``)."""
+        """The running fp16 accumulation ``[N, S, Q]`` after the most recently yielded layer of the most recently advanced
+        ``find_examples`` generator (the reference's ``intensity_accumulation``)."""
+        if self._acc is None:
+            raise RuntimeError("accumulated(): no find_examples step has run yet")
         return self._acc[:, :, :Q]

@@ -82,7 +82,7 @@ int main(int argc, char **argv)
 
     CHECK_RQAE(rqae_hip_pack(packed, d, c, K, L, w_in, b_in, cb, w_out, b_out, 1, stream));
     CHECK_RQAE(rqae_hip_encode(packed, d, c, K, L, x, RQAE_X_F32, n, levels, (float *)q, (int64_t *)idx, stream));
-    CHECK_RQAE(rqae_hip_decode(packed, d, c, K, L, idx, RQAE_IDX_I64, n, levels, NULL, (float *)dec, stream));
+    CHECK_RQAE(rqae_hip_decode(packed, d, c, K, L, idx, RQAE_IDX_I64, n, levels, NULL, (float *)dec, NULL /* status word */, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     /* error path: a shape the library refuses must come back as a code + message, not an abort */
     if (rqae_hip_encode(packed, 100000, c, K, L, x, RQAE_X_F32, n, levels, (float *)q, (int64_t *)idx, stream) == 0 ||

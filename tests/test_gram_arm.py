@@ -86,7 +86,9 @@ def test_gram_fixtures_tier2(name, dtype):
     if dtype != torch.float16:      # the capture is of the reference on exactly these inputs
         ref = g["codes"].astype(np.int64)
         bad = (idx != ref).any(axis=1)
-        assert bad.sum() <= max(listed, 0) + 2, f"{bad.sum()} tokens differ from the reference capture, {listed} listed"
+        # the oracle equals the capture on every fixture token (tests/test_oracle_golden.py), so the tokens that differ from the
+        # capture are exactly the ones check_tier2 listed against the oracle
+        assert bad.sum() == listed, f"{bad.sum()} tokens differ from the reference capture, {listed} listed"
         ok = ~bad
         rows = g["rows"][ok[g["rows"]]]
         sel = np.isin(g["rows"], rows)
@@ -113,16 +115,16 @@ def test_new_entry_points_reject_bad_arguments():
     vp = ctypes.c_void_p
     buf = torch.zeros(4096, dtype=torch.uint8, device=DEV)
     bad = [
-        L.rqae_hip_decode_gram(None, 2304, 5, 1024, 8, 1, buf.data_ptr(), 0, 4, 8, buf.data_ptr(), None),            # packed NULL
-        L.rqae_hip_decode_gram(buf.data_ptr(), 2304, 5, 1024, 8, 1, buf.data_ptr(), 7, 4, 8, buf.data_ptr(), None),  # bad index type
-        L.rqae_hip_decode_gram(buf.data_ptr(), 2304, 5, 4096, 32, 1, buf.data_ptr(), 0, 4, 32, buf.data_ptr(), None),  # more than one level group
+        L.rqae_hip_decode_gram(None, 2304, 5, 1024, 8, 1, buf.data_ptr(), 0, 4, 8, buf.data_ptr(), None, None),            # packed NULL
+        L.rqae_hip_decode_gram(buf.data_ptr(), 2304, 5, 1024, 8, 1, buf.data_ptr(), 7, 4, 8, buf.data_ptr(), None, None),  # bad index type
+        L.rqae_hip_decode_gram(buf.data_ptr(), 2304, 5, 4096, 32, 1, buf.data_ptr(), 0, 4, 32, buf.data_ptr(), None, None),  # more than one level group
         L.rqae_hip_search_query_table(buf.data_ptr(), 8, 625, buf.data_ptr(), 129, 8, 0, 4, buf.data_ptr(), None),   # Q > 128
         L.rqae_hip_search_query_table(buf.data_ptr(), 8, 625, buf.data_ptr(), 127, 8, 4, 9, buf.data_ptr(), None),   # levels past L
-        L.rqae_hip_search_accumulate(buf.data_ptr(), 0, 16, 8, buf.data_ptr(), 625, 127, 0, 4, buf.data_ptr(), 1, None),   # int64 codes
-        L.rqae_hip_search_accumulate(buf.data_ptr(), 2, 16, 8, buf.data_ptr(), 5000, 127, 0, 4, buf.data_ptr(), 1, None),  # K too large
-        L.rqae_hip_search_accumulate(buf.data_ptr(), 2, 16, 8, buf.data_ptr(), 625, 127, 3, 3, buf.data_ptr(), 1, None),   # empty range
+        L.rqae_hip_search_accumulate(buf.data_ptr(), 0, 16, 8, buf.data_ptr(), 625, 127, 0, 4, buf.data_ptr(), 1, None, None),   # int64 codes
+        L.rqae_hip_search_accumulate(buf.data_ptr(), 2, 16, 8, buf.data_ptr(), 5000, 127, 0, 4, buf.data_ptr(), 1, None, None),  # K too large
+        L.rqae_hip_search_accumulate(buf.data_ptr(), 2, 16, 8, buf.data_ptr(), 625, 127, 3, 3, buf.data_ptr(), 1, None, None),   # empty range
         L.rqae_hip_search_rank(buf.data_ptr(), 4, 3, 127, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 16, None),       # workspace too small
-        L.rqae_hip_search_gather(buf.data_ptr(), 4, 3, 200, buf.data_ptr(), 2, buf.data_ptr(), None),                      # Q > 128
+        L.rqae_hip_search_gather(buf.data_ptr(), 4, 3, 200, buf.data_ptr(), 2, buf.data_ptr(), None, None),                      # Q > 128
     ]
     assert all(rc != 0 for rc in bad), bad
     assert L.rqae_hip_last_error()
@@ -405,7 +407,7 @@ def test_arm_auto_switches_on_batch_size():
 
 @pytest.mark.parametrize("variant", ["fused", "pipelined", "first kernels", "lean chain, 8 waves", "first level chain"])
 def test_gram_kernel_variants(variant):
-    """Every kernel selection of the arm (rqae_hip_gram_configure) under the same Tier-2 bar, at a size that spans several
+    """Every kernel selection of the arm (rqae_hip_gram_options, handed over per call) under the same Tier-2 bar, at a size that spans several
     tiles / passes and a ragged end; the defaults are what every other test in this file runs."""
     cfg = synth.CONFIGS["C2"]
     w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
@@ -413,27 +415,17 @@ def test_gram_kernel_variants(variant):
     n = 70000 + 77
     x = np.concatenate([synth.activations(900 + i, min(32768, n - s), cfg["dim"]) for i, s in enumerate(range(0, n, 32768))])
     sel = np.unique(np.concatenate([np.arange(0, n, 61), np.arange(n - 300, n)]))
-    try:
-        if variant == "fused":
-            _native.gram_configure(fused=1)
-        elif variant == "pipelined":
-            _native.gram_configure(pipe_chunk=16384)
-        elif variant == "first kernels":
-            _native.gram_configure(proj=2, recon=1)
-        elif variant == "lean chain, 8 waves":
-            _native.gram_configure(lean_levels=1)
-        else:
-            _native.gram_configure(lean_levels=0)
-        for dt in (torch.bfloat16, torch.float16, torch.float32):
-            q, idx, xs = run(m, x, dt)
-            check_tier2(xs[sel], w, q[sel], idx[sel])
-            with torch.inference_mode():
-                only = m.encode(torch.from_numpy(x).to(DEV).to(dt).view(1, n, -1))
-            assert np.array_equal(only.cpu().numpy().reshape(n, -1), idx)
-        q3, i3, xs = run(m, x[:5000], torch.bfloat16, max_layers=3)
-        check_tier2(xs, w, q3, i3, levels=3)
-    finally:
-        _native.gram_configure(fused=0, pipe_chunk=0, proj=3, recon=2, lean_levels=2)
+    m.gram_options = {"fused": _native.gram_options(fused=1), "pipelined": _native.gram_options(pipe_chunk=16384),
+                      "first kernels": _native.gram_options(proj=2, recon=1), "lean chain, 8 waves": _native.gram_options(lean_levels=1),
+                      "first level chain": _native.gram_options(lean_levels=0)}[variant]     # per call, no process-wide switch
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        q, idx, xs = run(m, x, dt)
+        check_tier2(xs[sel], w, q[sel], idx[sel])
+        with torch.inference_mode():
+            only = m.encode(torch.from_numpy(x).to(DEV).to(dt).view(1, n, -1))
+        assert np.array_equal(only.cpu().numpy().reshape(n, -1), idx)
+    q3, i3, xs = run(m, x[:5000], torch.bfloat16, max_layers=3)
+    check_tier2(xs, w, q3, i3, levels=3)
 
 
 def test_operators_match_the_module_bit_for_bit():
@@ -461,26 +453,98 @@ def test_operators_match_the_module_bit_for_bit():
         assert torch.equal(cv, cv2) and torch.equal(k, k2)
 
 
-def test_out_of_range_codes_assert_on_the_device():
-    """decode with a code >= K: the reference raises IndexError; here the range check is a device-side assertion (no host
-    synchronisation on the good path).  A failed device assertion poisons the process, so this runs in a child."""
-    import subprocess
-    import sys
-    import os
+def test_operators_see_weights_restacked_after_an_update():
+    """stack, encode, modify the per-level weights in place, re-stack, encode -- the second call must use the
+    new weights (compared with a model loaded from them), also when the new stack reuses the old one's address; same for the
+    decode operator with a different codebook0 behind the same w_out / b_out."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(22, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    x = torch.from_numpy(synth.activations(6, 300, cfg["dim"])).to(DEV)
+    lv = {k: [torch.from_numpy(v[l]).to(DEV) for l in range(v.shape[0])] for k, v in w.items() if k != "codebook"}
+    cb = torch.from_numpy(w["codebook"]).to(DEV)
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys; sys.path.insert(0, %r)\n"
-        "import torch\n"
-        "from rqae_amd import RQAE\n"
-        "m = RQAE(dim=256, codebook_dim=4, codebook_size=4, num_quantizers=2).eval().to('cuda:0')\n"
-        "ok = torch.zeros(1, 8, 2, dtype=torch.long, device='cuda:0')\n"
-        "m.decode(ok); torch.cuda.synchronize(); print('good codes pass', flush=True)\n"
-        "bad = ok.clone(); bad[0, 3, 1] = 256\n"
-        "try:\n"
-        "    m.decode(bad); torch.cuda.synchronize(); print('NOT CAUGHT', flush=True)\n"
-        "except Exception as e:\n"
-        "    print('caught', type(e).__name__, flush=True)\n" % root)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert "good codes pass" in r.stdout, r.stdout + r.stderr
-    assert "NOT CAUGHT" not in r.stdout and ("caught" in r.stdout or r.returncode != 0), r.stdout + r.stderr
+    def run():
+        st = {k: torch.stack(v) for k, v in lv.items()}          # temporaries, as a caller holding per-level Linears makes them
+        with torch.inference_mode():
+            return torch.ops.rqae_hip.encode(x, st["w_in"], st["b_in"], cb, st["w_out"], st["b_out"], 99, True)
+
+    q1, i1 = run()
+    for t in lv["w_in"]:
+        t.mul_(-1.0)                                             # "optimizer step": every projection flips sign
+    for t in lv["b_in"]:
+        t.mul_(-1.0)
+    q2, i2 = run()
+    w2 = dict(w, w_in=-w["w_in"], b_in=-w["b_in"])
+    m2 = make_model(cfg, w2, "exact")
+    with torch.inference_mode():
+        qr, ir = m2(x.view(1, 300, -1))
+    assert torch.equal(i2, ir[0]) and torch.equal(q2, qr[0])
+    assert not torch.equal(i1, i2)
+    # decode: same w_out / b_out objects, another codebook0
+    st = {k: torch.stack(v) for k, v in lv.items()}
+    none = torch.empty(0, dtype=torch.bool, device=DEV)
+    with torch.inference_mode():
+        d1 = torch.ops.rqae_hip.decode(ir[0], cb[0], st["w_out"], st["b_out"], none)
+        d2 = torch.ops.rqae_hip.decode(ir[0], cb[0] * 0.5, st["w_out"], st["b_out"], none)
+        cb_half = cb[0] * 0.5
+        d3 = torch.ops.rqae_hip.decode(ir[0], cb_half, st["w_out"], st["b_out"], none)
+    assert torch.equal(d2, d3) and not torch.equal(d1, d2)
+    assert torch.equal(d1, m2.decode(ir)[0])
+
+
+def test_out_of_range_codes_raise_index_error_and_the_process_lives():
+    """decode / intensity with a code outside the codebook: the reference raises IndexError (rqae/model.py:234,
+    rqae/feature.py:120), a recoverable error.  Here the kernels read row 0 instead of out of bounds and set the status word
+    (include/rqae_hip.h), the wrapper raises IndexError from it -- in THIS process, which then keeps working.  Every index
+    dtype, both decode arms, a size past 2^24 elements; negative codes count from the end as in torch indexing."""
+    from rqae_amd import RQAEFeature
+
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(23, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    K = 1024
+    for arm, n in (("exact", 300), ("gram", 20000), ("exact", 2200000)):
+        m = make_model(cfg, w, arm)
+        g = torch.Generator(device=DEV); g.manual_seed(n)
+        good = torch.randint(0, K, (1, n, 8), device=DEV, generator=g)
+        ref = m.decode(good)
+        for dt in (torch.int64, torch.int32, torch.uint16):
+            gi = good.to(torch.int32).to(torch.int16).view(torch.uint16) if dt == torch.uint16 else good.to(dt)
+            assert torch.equal(m.decode(gi), ref)
+            bad = good.clone()
+            bad[0, n - 3, 5] = K if dt == torch.uint16 else K + (1 << 20)
+            bi = bad.to(torch.int32).to(torch.int16).view(torch.uint16) if dt == torch.uint16 else bad.to(dt)
+            if dt == torch.uint16:
+                bi = bi.clone(); bi.view(torch.int16)[0, n - 3, 5] = K      # 1024 as a uint16 code
+            with pytest.raises(IndexError, match="out of range"):
+                m.decode(bi)
+            assert torch.equal(m.decode(gi), ref)                            # the same process carries on, results intact
+        if n < 100000:
+            neg = good.clone()
+            neg[0, 7, 2] = good[0, 7, 2] - K                                 # torch indexing: -K <= code < 0 counts from the end
+            assert torch.equal(m.decode(neg), ref)
+            neg[0, 7, 2] = -K - 1
+            with pytest.raises(IndexError):
+                m.decode(neg)
+    # intensity
+    cfg_p = dict(dim=256, codebook_dim=4, codebook_size=5, num_quantizers=16)
+    mp = RQAE(**cfg_p).eval().to(DEV)
+    feat = RQAEFeature.from_quantizer(mp, center=torch.randint(0, 625, (16,)), layers=list(range(2, 16)))
+    codes = torch.randint(0, 625, (5000, 16), device=DEV)
+    out = feat.intensity(codes, [3, 9, 15])
+    codes_bad = codes.clone(); codes_bad[4321, 8] = 625
+    with pytest.raises(IndexError, match="out of range"):
+        feat.intensity(codes_bad, [3, 9, 15])
+    assert torch.equal(feat.intensity(codes, [3, 9, 15]), out)
+    # lazy mode: no synchronisation at the call, the error surfaces at check_status() (or the next call that takes codes)
+    m = make_model(cfg, w, "exact")
+    _native.set_code_check("lazy")
+    try:
+        small = torch.zeros(1, 8, 8, dtype=torch.long, device=DEV)
+        small[0, 1, 1] = K
+        m.decode(small)                                                      # queued, not raised
+        with pytest.raises(IndexError):
+            _native.check_status()
+        m.decode(torch.zeros(1, 8, 8, dtype=torch.long, device=DEV))
+        _native.check_status()
+    finally:
+        _native.set_code_check("sync")

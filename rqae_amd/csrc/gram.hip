@@ -161,6 +161,42 @@ __device__ inline uint16_t piece_of(float v, int part)
     split3(v, h, m, l);
     return (uint16_t)((part == 0 ? h : part == 1 ? m : l) >> 16);
 }
+// q / ||q|| as the reference forms it before the cosine product (rqae/model.py:188: `x / x.norm(dim=-1, keepdim=True)`), with
+// torch-CPU's order of the 2-norm written out (oracle/rqae_oracle.c: aten_norm2 -- whole groups of 8 as fma lanes summed in lane
+// order, one group of 4 as rounded squares, an fma tail), IEEE square root and divisions.  The exact rescoring dots THIS vector
+// with the candidate rows, so two distinct rows whose fp32 cosines tie or differ in the last bit resolve as they do in the
+// reference (a zero projection gives NaN here as there; the callers' okq sends it to index 0).
+template <int CP>
+__device__ __forceinline__ void unit_dir(const float (&q)[CP], int c, float (&xn)[CP])
+{
+    float acc = 0.0f;
+    int d = 0;
+    if (c >= 8) {
+        float buf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d0 = 0; d0 + 8 <= CP; d0 += 8)
+            if (d0 + 8 <= c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) buf[j] = __builtin_fmaf(q[d0 + j], q[d0 + j], buf[j]);
+                d = d0 + 8;
+            }
+        acc = buf[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) acc = acc + buf[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CP; ++j) {
+        // the group of 4 (elements d .. d+3) as rounded squares, the rest as an fma tail; d is 0 or 8 for CP <= 16
+        const bool in4 = (c - d >= 4) && j >= d && j < d + 4;
+        const bool tail = j >= d + ((c - d >= 4) ? 4 : 0) && j < c;
+        if (in4) { const float sq = q[j] * q[j]; acc = acc + sq; }
+        else if (tail) acc = __builtin_fmaf(q[j], q[j], acc);
+    }
+    const float nrm = __builtin_sqrtf(acc);
+#pragma unroll
+    for (int j = 0; j < CP; ++j) xn[j] = j < c ? q[j] / nrm : 0.0f;
+}
+
 // the six products kept per component: (A piece, B piece); dropped: mid*lo, lo*mid, lo*lo (<= 2^-24 relative)
 __device__ constexpr int APART[6] = {0, 0, 1, 0, 2, 1};
 // B side per component, slot order: hi mid hi lo hi mid  -> dwords {hi|mid, hi|lo, hi|mid}
@@ -787,6 +823,8 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
 #pragma unroll
                     for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
                     const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
+                    float xn[CP];
+                    unit_dir<CP>(q, c, xn);
 
                     // ---- B operand rows of this wave's tokens: 32 slots = 64 bytes per token, through LDS
                     unsigned dw[16];
@@ -916,7 +954,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
                         for (int r = 0; r < 4; ++r) {
                             float s = 0.0f;
 #pragma unroll
-                            for (int j = 0; j < CP; ++j) s = __builtin_fmaf(f[r * CP + j], q[j], s);
+                            for (int j = 0; j < CP; ++j) s = __builtin_fmaf(xn[j], f[r * CP + j], s);
                             const bool up = (s > bsc) && (r0 + r < p.K);
                             bsc = up ? s : bsc;
                             brow = up ? r0 + r : brow;

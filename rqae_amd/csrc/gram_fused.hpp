@@ -409,6 +409,8 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
                 const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
+                float xn[CP];
+                unit_dir<CP>(q, c, xn);      // the reference's q / ||q|| (rqae/model.py:188): what the exact rescoring multiplies the rows by
                 if (li == 1) F_STAMPA(30, 0);
                 // ---- B operand rows of the wave's 32 tokens: 32 slots = 64 bytes per token
                 {
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                         for (int r = 0; r < 4; ++r) {
                             float acc_s = 0.0f;
 #pragma unroll
-                            for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(f[r * CP + j], q[j], acc_s);
+                            for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(xn[j], f[r * CP + j], acc_s);
                             // rows past K (copies of row 0 in LDS) lose to everything; a NaN score loses too (okq handles NaN rows)
                             sc[4 * i + r] = (r0 + r < p.K) ? acc_s : -INFINITY;
                             rw[4 * i + r] = r0 + r;
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                             for (int r = 0; r < 4; ++r) {
                                 float acc_s = 0.0f;
 #pragma unroll
-                                for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f, q[j], acc_s);
+                                for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(xn[j], j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f, acc_s);
                                 const bool up = (acc_s > bsc) && (r0 + r < p.K);
                                 bsc = up ? acc_s : bsc;
                                 brow = up ? r0 + r : brow;
@@ -871,6 +873,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
     }
     const int wq = (lane >> 2) & 3;
     const int ngrp = p.KTP / 4;
+    const bool kragged = (p.K & 15) != 0;
     for (long long tile = (long long)blockIdx.x * NW + wave; tile < p.ntiles; tile += (long long)gridDim.x * NW) {
         const long long t = tile * 64 + lane;          // < tok_pad
         float Q[GL][CP];
@@ -905,6 +908,8 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
                 const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
+                float xn[CP];
+                unit_dir<CP>(q, c, xn);      // the reference's q / ||q|| (rqae/model.py:188): what the exact rescoring multiplies the rows by
                 {   // B operand rows of the wave's 64 tokens: 32 slots = 64 bytes per token
                     unsigned dw[16];
 #pragma unroll
@@ -1032,10 +1037,16 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                         for (int r = 0; r < 4; ++r) {
                             float acc_s = 0.0f;
 #pragma unroll
-                            for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(f[r * CP + j], q[j], acc_s);
-                            sc[4 * i + r] = (r0 + r < p.K) ? acc_s : -INFINITY;
+                            for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(xn[j], f[r * CP + j], acc_s);
+                            sc[4 * i + r] = acc_s;
                             rw[4 * i + r] = r0 + r;
                         }
+                    }
+                    // rows past K exist only in the last row tile of a codebook whose size is no multiple of 16 (a wave-uniform fact):
+                    // they never win
+                    if (kragged) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) sc[k] = rw[k] < p.K ? sc[k] : -INFINITY;
                     }
 #pragma unroll
                     for (int st2 = 1; st2 < 16; st2 *= 2)
@@ -1059,7 +1070,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                             for (int r = 0; r < 4; ++r) {
                                 float acc_s = 0.0f;
 #pragma unroll
-                                for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f, q[j], acc_s);
+                                for (int j = 0; j < CP; ++j) acc_s = __builtin_fmaf(xn[j], j < c ? cbf[(size_t)(r0 + r) * c + j] : 0.0f, acc_s);
                                 const bool up = (acc_s > bsc) && (r0 + r < p.K);
                                 bsc = up ? acc_s : bsc;
                                 brow = up ? r0 + r : brow;

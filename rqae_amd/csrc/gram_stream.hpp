@@ -85,6 +85,8 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_stream_kernel(LevParams p
 #pragma unroll
                     for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
                     const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
+                    float xn[CP];
+                    unit_dir<CP>(q, c, xn);      // the reference's q / ||q|| (rqae/model.py:188): what the exact rescoring multiplies the rows by
                     {
                         unsigned dw[16];
 #pragma unroll

@@ -152,36 +152,67 @@ class RQAE(nn.Module):
         state["_gram_ws"] = None
         state["gram_options"] = None      # a ctypes struct: not picklable, and a per-process tuning choice anyway
         state.pop("_param_list", None)
+        state.pop("_key_state", None)
         return state
 
     def _dims(self):
         return (self._dim, self.codebook_dim, self.codebook.shape[1], self.num_quantizers)
 
+    _KEY_WALK_ALL = 512      # parameter tensors up to which every call checks every one of them
+    _KEY_SLICES = 16         # beyond that, in eval mode: one sixteenth of the list per call, round robin
+
     def _weights_key(self):
-        """Fingerprint of the parameters the packed blocks were built from: device, mode, and for EVERY parameter
-        tensor its storage pointer and version counter (the reference reads the weights live at every call,
-        rqae/model.py:199-230, so an in-place edit of any level must be seen).  The tensors are walked through a
-        cached flat list -- ~40 us for the 4097 tensors of the pretrained shape, far below a 512-token encode.
-        A ``.data`` write that keeps the storage (``p.data.copy_``) bumps no counter: call ``invalidate_packed()``
-        after one."""
+        """Fingerprint of the parameters the packed blocks were built from: device, mode, and the storage pointers and version
+        counters of the parameter tensors (the reference reads the weights live at every call, rqae/model.py:199-230, so an
+        in-place edit of any level must be seen).
+
+        Cost: the walk is a Python loop, 0.7 ms for the 4097 tensors of the pretrained shape (measured; 0.17 us per tensor) --
+        a fifth of a 512-token hook call.  So: up to 512 tensors (every BASELINE config), or while ``self.training``, EVERY
+        tensor is checked at EVERY call.  A larger module in eval mode checks the codebook and one sixteenth of the list per
+        call, round robin: ``load_state_dict`` / ``.to()`` / ``_apply`` drop the cache at once as before, an in-place edit of one
+        level's weights in eval mode is seen within 16 calls -- call ``invalidate_packed()`` to see it at the next one.  A
+        ``.data`` write that keeps the storage (``p.data.copy_``) bumps no counter: ``invalidate_packed()`` as well."""
         plist = self.__dict__.get("_param_list")
         if plist is None or len(plist) != 4 * len(self.layers) + 1:
             plist = [self.codebook]
             for lin_in, lin_out in self.layers:
                 plist += [lin_in.weight, lin_in.bias, lin_out.weight, lin_out.bias]
             self.__dict__["_param_list"] = plist
-        ver = 0
-        ptr = 0
-        for t in plist:
-            ver += t._version
-            ptr ^= t.data_ptr()
-        return (self.codebook.device, self.training, ptr, ver, len(plist))
+            self.__dict__["_key_state"] = None
+        n = len(plist)
+        if n <= self._KEY_WALK_ALL or self.training:
+            ver = 0
+            ptr = 0
+            for t in plist:
+                ver += t._version
+                ptr ^= t.data_ptr()
+            return (self.codebook.device, self.training, ptr, ver, n)
+        # large module, eval mode: per-tensor snapshot, one slice re-read per call; the key carries a generation number that moves
+        # whenever a re-read tensor differs from its snapshot
+        st = self.__dict__.get("_key_state")
+        if st is None or len(st["snap"]) != n:
+            st = {"snap": [(t._version, t.data_ptr()) for t in plist], "gen": 0, "turn": 0}
+            self.__dict__["_key_state"] = st
+        else:
+            snap, k = st["snap"], st["turn"]
+            changed = False
+            for i in [0, *range(1 + k, n, self._KEY_SLICES)]:
+                t = plist[i]
+                cur = (t._version, t.data_ptr())
+                if cur != snap[i]:
+                    snap[i] = cur
+                    changed = True
+            st["turn"] = (k + 1) % self._KEY_SLICES
+            if changed:
+                st["gen"] += 1
+        return (self.codebook.device, self.training, st["gen"], n)
 
     def invalidate_packed(self):
         """Drop the packed parameter blocks (call after a ``.data`` write that the version counters cannot see)."""
         self._packed = None
         self._gram = None
         self.__dict__.pop("_param_list", None)
+        self.__dict__.pop("_key_state", None)
 
     def _stacked(self):
         w_in = torch.stack([l[0].weight for l in self.layers]).float().contiguous()

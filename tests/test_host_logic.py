@@ -123,6 +123,25 @@ def test_weights_key_sees_every_parameter():
     k1 = m._weights_key()
     m.layers[2][1].bias.data = m.layers[2][1].bias.data.clone()   # new storage
     assert m._weights_key() != k1
+    # a module with more than 512 parameter tensors in eval mode re-reads a sixteenth of them per call (the full
+    # walk cost 0.7 ms per call at the pretrained shape): an in-place edit is seen within 16 calls, at once after
+    # invalidate_packed(), and at every call while training
+    big = RQAE(dim=8, codebook_dim=2, codebook_size=2, num_quantizers=200).eval()
+    k0 = big._weights_key()
+    assert big._weights_key() == k0
+    with torch.no_grad():
+        big.layers[137][1].weight.add_(1.0)
+    keys = [big._weights_key() for _ in range(16)]
+    assert keys[-1] != k0 and len(set(keys)) == 2           # one change of key, no flapping
+    with torch.no_grad():
+        big.layers[5][0].bias.add_(1.0)
+    big.invalidate_packed()
+    assert big._packed is None and big._gram is None
+    big.train()
+    k1 = big._weights_key()
+    with torch.no_grad():
+        big.layers[77][0].weight.add_(1.0)
+    assert big._weights_key() != k1
     with pytest.raises(ValueError):
         RQAE(dim=16, codebook_dim=2, codebook_size=3, num_quantizers=1, arm="fast")
     assert RQAE(dim=16, codebook_dim=2, codebook_size=3, num_quantizers=1, arm="gram").arm == "gram"

@@ -181,7 +181,7 @@ def test_find_examples_full_shard_properties():
     for (out, layer), (_, _, o_acc, _) in zip(eng.find_examples(idx=5, layers=layers), o_steps):
         acc = eng.accumulated(S)
         assert np.array_equal(bits(acc[sample].cpu().numpy()), bits(o_acc)), layer
-        mx, order, _ = __import__("rqae_amd")._native.search_rank(eng._acc, S)
+        mx, order, _ = __import__("rqae_amd")._native.search_rank(eng._acc, S)      # the LDS bitonic rank on its own
         ref_max = acc.float().amax(dim=1).T                                           # [Q, N]
         assert torch.equal(torch.sort(order, dim=1).values, torch.arange(N, device=order.device, dtype=torch.int32).expand(S, N))
         assert torch.equal(mx.float(), torch.gather(ref_max, 1, order.long()))
@@ -245,3 +245,112 @@ def test_find_examples_errors():
         next(eng.find_examples(idx=1, layers=[4, 4]))
     with pytest.raises(IndexError):
         next(eng.find_examples(idx=7, layers=[4]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,S,Q", [(1, 3, 5), (2, 1, 1), (47, 5, 127), (1024, 4, 127), (8192, 2, 9), (8193, 2, 3), (20000, 1, 4), (70001, 1, 2)])
+def test_rank_is_the_stable_descending_order(N, S, Q):
+    """rqae_hip_search_rank (the hand-written bitonic sort: one chunk in LDS up to 8192 sequences, chunks merged through global
+    memory beyond) against numpy's stable argsort of the row maxima: descending, equal maxima in ascending sequence order, NaN
+    on top, -0 ranked with +0; few distinct values so that ties are everywhere."""
+    from rqae_amd import _native
+
+    rng = np.random.default_rng(N * 131 + Q)
+    vals = rng.integers(-6, 7, size=(N, S, 128)).astype(np.float16) * np.float16(0.5)
+    vals[rng.random((N, S, 128)) < 0.02] = np.float16(-0.0)
+    if N > 3:
+        vals[N // 3, :, 0] = np.float16("nan")
+        vals[N // 2, 0, 1 % Q] = np.float16("inf")
+        vals[N - 1, :, 0] = np.float16("-inf")
+    acc = torch.from_numpy(vals).to("cuda:0")
+    mx, order, ws = _native.search_rank(acc, Q)
+    torch.cuda.synchronize()
+    m = np.fmax.reduce(vals.astype(np.float32), axis=1)[:, :Q]                  # [N, Q]; NaN takes the maximum, like torch.max
+    nan_row = np.isnan(vals.astype(np.float32)).any(axis=1)[:, :Q]
+    m[nan_row] = np.nan
+    key = np.where(np.isnan(m), np.inf, m)
+    tie_break = np.where(np.isnan(m), 1, 0)                                      # NaN ranks above +inf
+    want = np.stack([np.lexsort((np.arange(N), -key[:, q], -tie_break[:, q])) for q in range(Q)])   # NaN, then descending, then n
+    got = order.cpu().numpy()
+    assert np.array_equal(got, want.astype(np.int32))
+    gm = mx.cpu().numpy().astype(np.float32)
+    wm = np.take_along_axis(m.T, want, axis=1)
+    assert np.array_equal(np.isnan(gm), np.isnan(wm)) and np.array_equal(gm[~np.isnan(gm)], wm[~np.isnan(wm)])
+    mx2, order2, _ = _native.search_rank(acc, Q, ws)                                 # workspace reuse: same answer
+    assert torch.equal(order2, order)
+
+
+@pytest.mark.gpu
+def test_two_live_generators_do_not_share_state():
+    """ADVICE round 2: the server streams find_examples through remote_gen, so two generators of one engine can be live at once;
+    each keeps its own accumulation (as the reference does, server.py:206).  Interleaved = run one after the other."""
+    from rqae_amd.search import IntensityEngine
+
+    g = torch.Generator(device="cpu").manual_seed(12)
+    N, S, L, K = 96, 31, 40, 625
+    codes = torch.randint(0, K, (N, S, L), generator=g, dtype=torch.int32)
+    sims16 = (torch.rand((L, K, K), generator=g) * 2 - 1).to(torch.float16)
+    eng = IntensityEngine(sims16, codes, device="cuda:0")
+    layers = [4, 9, 40]
+    alone_a = [(o["top"]["indices"].clone(), o["bottom"]["intensities"].clone()) for o, _ in eng.find_examples(idx=3, layers=layers)]
+    alone_b = [(o["top"]["indices"].clone(), o["bottom"]["intensities"].clone()) for o, _ in eng.find_examples(idx=77, layers=layers)]
+    ga, gb = eng.find_examples(idx=3, layers=layers), eng.find_examples(idx=77, layers=layers)
+    for step in range(len(layers)):
+        oa, _ = next(ga)
+        ob, _ = next(gb)
+        assert torch.equal(oa["top"]["indices"], alone_a[step][0]) and torch.equal(oa["bottom"]["intensities"], alone_a[step][1])
+        assert torch.equal(ob["top"]["indices"], alone_b[step][0]) and torch.equal(ob["bottom"]["intensities"], alone_b[step][1])
+
+
+@pytest.mark.gpu
+def test_example_slices_follow_the_reference():
+    """server.py:268-280 slices the ranking with [:top], [mid0:mid1] and [-bottom:]; `[-0:]` is the whole ranking."""
+    from rqae_amd.search import IntensityEngine
+
+    g = torch.Generator(device="cpu").manual_seed(13)
+    N, S, L, K = 12, 7, 8, 50
+    codes = torch.randint(0, K, (N, S, L), generator=g, dtype=torch.int32)
+    sims16 = (torch.rand((L, K, K), generator=g) * 2 - 1).to(torch.float16)
+    eng = IntensityEngine(sims16, codes, device="cuda:0")
+    full = np.arange(N)
+    for top, mid, bot in ((3, 2, 0), (0, 0, 2), (20, 30, 40), (1, 3, 1)):
+        out, _ = next(eng.find_examples(idx=2, top_examples=top, middle_examples=mid, bottom_examples=bot, layers=[8]))
+        assert out["top"]["indices"].shape[1] == len(full[:top])
+        assert out["middle"]["indices"].shape[1] == len(full[N // 2 - mid // 2: N // 2 + mid // 2])
+        assert out["bottom"]["indices"].shape[1] == len(full[-bot:])
+        assert out["bottom"]["intensities"].shape == (S, len(full[-bot:]), S)
+
+
+@pytest.mark.gpu
+def test_bad_dataset_codes_and_examples_raise_index_error():
+    """A dataset code outside the table: the reference's gather raises IndexError (server.py:55); here the accumulate kernel
+    flags the call (include/rqae_hip.h "Status word") and the wrapper raises IndexError; the process carries on.  Same for an
+    example index outside the dataset in the gather."""
+    from rqae_amd import _native
+    from rqae_amd.search import IntensityEngine
+
+    g = torch.Generator(device="cpu").manual_seed(14)
+    N, S, L, K = 40, 9, 16, 625
+    codes = torch.randint(0, K, (N, S, L), generator=g, dtype=torch.int32)
+    sims16 = (torch.rand((L, K, K), generator=g) * 2 - 1).to(torch.float16)
+    good = [o["top"]["indices"].clone() for o, _ in IntensityEngine(sims16, codes, device="cuda:0").find_examples(idx=1, layers=[4, 16])]
+    for bad_value, dt in ((K, torch.int32), (K + 3, torch.int32), (70000, torch.int32), (-1, torch.int32)):
+        bad = codes.clone()
+        bad[17, 4, 9] = bad_value
+        if bad_value < 0 or bad_value > 65535:
+            with pytest.raises(IndexError):
+                IntensityEngine(sims16, bad, device="cuda:0")                   # caught at load (the uint16 fold would hide it)
+            continue
+        eng = IntensityEngine(sims16, bad, device="cuda:0")
+        gen = eng.find_examples(idx=1, layers=[4, 16])
+        next(gen)                                                                # levels 0..3: clean
+        with pytest.raises(IndexError, match="out of range"):
+            next(gen)                                                            # level 9 lies in the second range
+    eng = IntensityEngine(sims16, codes, device="cuda:0")
+    assert [o["top"]["indices"] for o, _ in eng.find_examples(idx=1, layers=[4, 16])][1].equal(good[1])
+    acc = torch.zeros((N, S, 128), dtype=torch.float16, device="cuda:0")
+    ex = torch.tensor([[0, N - 1, N]] * 5, dtype=torch.int32, device="cuda:0")
+    with pytest.raises(IndexError, match="outside the dataset"):
+        _native.search_gather(acc, 5, ex)
+    with pytest.raises(IndexError):
+        next(eng.find_examples(activation=torch.full((S, L), K, dtype=torch.int32), layers=[4]))    # the query's own codes

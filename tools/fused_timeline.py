@@ -21,11 +21,13 @@ def main():
     import __graft_entry__ as ge
     out = os.path.join(ROOT, "tools", "_build")
     os.makedirs(out, exist_ok=True)
-    obj = os.path.join(out, "gram_tl.o")
     so = os.path.join(out, "librqae_hip_tl.so")
-    subprocess.run(["/opt/rocm/bin/hipcc", *ge.HIPCC_FLAGS, "-DRQAE_FUSED_TIMELINE", *[f"-D{m}" for m in args.define], "-c", os.path.join(CSRC, "gram.hip"), "-o", obj], check=True)
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(CSRC, "rqae_hip.o"),
-                    os.path.join(CSRC, "encode_main.o"), obj, "-o", so], check=True)
+    objdir = os.path.join(out, "tl_obj")
+    os.makedirs(objdir, exist_ok=True)
+    for f in ("rqae_hip.o", "encode_main.o", "search.o"):       # unchanged units: the product build's objects
+        shutil.copy(os.path.join(CSRC, f), os.path.join(objdir, f))
+    ge.build_library(so, extra_flags=["-DRQAE_FUSED_TIMELINE", "-DRQAE_GRAM_TOOLS", *[f"-D{m}" for m in args.define]], objdir=objdir,
+                     units=("gram.hip",))
     import numpy as np
     import torch
     from rqae_amd import _native, synth

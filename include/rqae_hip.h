@@ -205,7 +205,9 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
 int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared);
 size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared);
 int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
-                       const float *codebook, const float *w_out, const float *b_out, int codebook_shared, void *stream);
+                       const float *codebook, const float *w_out, const float *b_out, int codebook_shared,
+                       const float *in_scale /* [d] or NULL: a diagonal map in front of lin_in, folded into the W_in image */,
+                       void *stream);
 size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels);
 /* Which kernels one rqae_hip_encode_gram call launches: per call, no process-wide state (NULL = the defaults, in
  * parentheses; a negative field keeps its default).  Every combination computes the same function under the same parity
@@ -225,6 +227,16 @@ typedef struct rqae_hip_gram_options {
 int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
                          int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace,
                          const rqae_hip_gram_options *options, void *stream);
+/* The step in front of forward inside RQAE.hook when the LLM is Gemma-2 (rqae/model.py:279-281; Gemma2.norm, rqae/llm.py:65-66),
+ * on the matrix-core arm: hs [n_tokens][d] bf16 / fp16 is the hooked layer's output itself.  The norm is linear in front of
+ * lin_in: normed = (hs rs)(1 + w), rs = 1 / sqrt(mean(hs^2) + eps) per token, so the caller packs with in_scale = 1 + w
+ * (rqae_hip_gram_pack) and the projection kernel sums hs^2 while the tile passes through its registers and scales the
+ * projections by rs; `normed` never exists in memory.  q_out / indices as rqae_hip_encode_gram (in normed space: the reference's
+ * `quantized`); inv_rms [n_tokens] fp32 receives rs for the way back (rqae_hip_gemma_denorm_patch).  Tier-2 parity. */
+int rqae_hip_encode_gram_gemma_supported(int d, int c, int K, int L, int codebook_shared, int hs_dtype);
+int rqae_hip_encode_gram_gemma(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *hs, int hs_dtype,
+                               float eps, int64_t n_tokens, int levels, float *q_out, int64_t *indices, float *inv_rms,
+                               void *workspace, const rqae_hip_gram_options *options, void *stream);
 /* RQAE.decode (rqae/model.py:250-252) on the matrix-core arm, every level of indices [n_tokens][levels] selected: the decode sum
  * as rqae_hip_encode_gram's reconstruction kernel computes it (bf16-piece products, fp32 accumulation: within 1e-6 relative of
  * rqae_hip_decode, not its bits), codebook rows gathered by the codes in the kernel.  HBM-write-bound: 9 216 + 8 levels bytes per

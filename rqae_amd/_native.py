@@ -44,6 +44,8 @@ SYMBOLS = (
     "rqae_hip_gram_pack",
     "rqae_hip_gram_workspace_bytes",
     "rqae_hip_encode_gram",
+    "rqae_hip_encode_gram_gemma_supported",
+    "rqae_hip_encode_gram_gemma",
     "rqae_hip_encode_gram_phases",
     "rqae_hip_decode_gram_supported",
     "rqae_hip_decode_gram",
@@ -125,12 +127,16 @@ def lib():
     L.rqae_hip_gram_supported.restype = i
     L.rqae_hip_gram_packed_bytes.argtypes = [i, i, i, i, i]
     L.rqae_hip_gram_packed_bytes.restype = sz
-    L.rqae_hip_gram_pack.argtypes = [vp, i, i, i, i, vp, vp, vp, vp, vp, i, vp]
+    L.rqae_hip_gram_pack.argtypes = [vp, i, i, i, i, vp, vp, vp, vp, vp, i, vp, vp]
     L.rqae_hip_gram_pack.restype = i
     L.rqae_hip_gram_workspace_bytes.argtypes = [i, i, i, i, i64, i]
     L.rqae_hip_gram_workspace_bytes.restype = sz
     L.rqae_hip_encode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, ctypes.POINTER(GramOptions), vp]
     L.rqae_hip_encode_gram.restype = i
+    L.rqae_hip_encode_gram_gemma_supported.argtypes = [i, i, i, i, i, i]
+    L.rqae_hip_encode_gram_gemma_supported.restype = i
+    L.rqae_hip_encode_gram_gemma.argtypes = [vp, i, i, i, i, i, vp, i, ctypes.c_float, i64, i, vp, vp, vp, vp, ctypes.POINTER(GramOptions), vp]
+    L.rqae_hip_encode_gram_gemma.restype = i
     L.rqae_hip_encode_gram_phases.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, ctypes.POINTER(GramOptions), vp,
                                               ctypes.POINTER(ctypes.c_float)]
     L.rqae_hip_encode_gram_phases.restype = i
@@ -232,8 +238,9 @@ def gram_supported(dims, codebook_shared: bool) -> bool:
     return bool(lib().rqae_hip_gram_supported(d, c, K, L_, int(bool(codebook_shared))))
 
 
-def gram_pack(w_in, b_in, codebook, w_out, b_out, codebook_shared: bool) -> torch.Tensor:
-    """Stacked fp32 parameters -> the gram arm's own device block (bf16 operand images, Gram blocks)."""
+def gram_pack(w_in, b_in, codebook, w_out, b_out, codebook_shared: bool, in_scale: torch.Tensor | None = None) -> torch.Tensor:
+    """Stacked fp32 parameters -> the gram arm's own device block (bf16 operand images, Gram blocks).  ``in_scale`` [d] fp32:
+    a diagonal map in front of lin_in folded into the W_in image (Gemma's ``1 + norm.weight`` for encode_gram_gemma)."""
     L_, c, d = w_in.shape
     K = codebook.shape[1]
     for n, t in (("w_in", w_in), ("b_in", b_in), ("codebook", codebook), ("w_out", w_out), ("b_out", b_out)):
@@ -245,9 +252,14 @@ def gram_pack(w_in, b_in, codebook, w_out, b_out, codebook_shared: bool) -> torc
         _check(1, "rqae_hip_gram_packed_bytes")
     out = torch.empty(nbytes, dtype=torch.uint8, device=w_in.device)
     with torch.cuda.device(w_in.device):
+        if in_scale is not None:
+            in_scale = in_scale.detach().to(device=w_in.device, dtype=torch.float32).contiguous()
+            if in_scale.numel() != d:
+                raise RuntimeError("gram_pack: in_scale must have d elements")
         rc = lib().rqae_hip_gram_pack(out.data_ptr(), d, c, K, L_, w_in.data_ptr(), b_in.data_ptr(),
                                       codebook.data_ptr(), w_out.data_ptr(), b_out.data_ptr(),
-                                      int(bool(codebook_shared)), _stream(w_in.device))
+                                      int(bool(codebook_shared)), in_scale.data_ptr() if in_scale is not None else None,
+                                      _stream(w_in.device))
     _check(rc, "rqae_hip_gram_pack")
     return out
 
@@ -281,6 +293,38 @@ def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels:
                                         _stream(x2d.device))
     _check(rc, "rqae_hip_encode_gram")
     return q, idx
+
+
+def encode_gram_gemma_supported(dims, hs_dtype) -> bool:
+    d, c, K, L_ = dims
+    return hs_dtype in _X_DTYPES and bool(lib().rqae_hip_encode_gram_gemma_supported(d, c, K, L_, 1, _X_DTYPES[hs_dtype]))
+
+
+def encode_gram_gemma(gpacked_scaled, dims, hs: torch.Tensor, eps: float, levels: int, workspace: torch.Tensor | None = None,
+                      options: GramOptions | None = None):
+    """hs [B,S,d] {bf16,f16} (the hooked layer's output) -> (q_out [B,S,d] f32, indices [B,S,levels] i64, inv_rms [B,S] f32):
+    Gemma RMSNorm + RQAE.forward on the matrix-core arm (rqae/model.py:279-281); ``gpacked_scaled`` = gram_pack(...,
+    in_scale=1 + norm.weight)."""
+    _require_cuda(hs, "hidden states")
+    if hs.dtype not in (torch.bfloat16, torch.float16) or not hs.is_contiguous() or hs.dim() != 3:
+        raise RuntimeError("encode_gram_gemma: hidden states must be contiguous [B,S,d] bf16/f16")
+    d, c, K, L_ = dims
+    B, S, _ = hs.shape
+    n = B * S
+    q = torch.empty((B, S, d), dtype=torch.float32, device=hs.device)
+    idx = torch.empty((B, S, levels), dtype=torch.int64, device=hs.device)
+    rs = torch.empty((B, S), dtype=torch.float32, device=hs.device)
+    if n:
+        need = gram_workspace_bytes(dims, n, levels)
+        if workspace is None or workspace.numel() * workspace.element_size() < need or workspace.device != hs.device:
+            workspace = torch.empty(need, dtype=torch.uint8, device=hs.device)
+        with torch.cuda.device(hs.device):
+            rc = lib().rqae_hip_encode_gram_gemma(gpacked_scaled.data_ptr(), d, c, K, L_, 1, hs.data_ptr(), _X_DTYPES[hs.dtype],
+                                                  float(eps), n, levels, q.data_ptr(), idx.data_ptr(), rs.data_ptr(),
+                                                  workspace.data_ptr(), ctypes.byref(options) if options is not None else None,
+                                                  _stream(hs.device))
+        _check(rc, "rqae_hip_encode_gram_gemma")
+    return q, idx, rs
 
 
 def decode_gram_supported(dims, codebook_shared: bool, levels: int) -> bool:
@@ -387,7 +431,7 @@ def _status_ptr(device):
     if _CHECK_MODE == "off":
         return None
     ent = _status_entry(device)
-    if _CHECK_MODE == "lazy" and int(ent[1][0]) != 0:
+    if _CHECK_MODE == "lazy" and int(ent[1][0]) != 0 and not torch.cuda.is_current_stream_capturing():
         _raise_flagged(ent)
     return ent[0].data_ptr()
 
@@ -405,6 +449,8 @@ def _codes_checked(device, message: str):
         return
     ent = _status_entry(device)
     ent[2][0] = message
+    if torch.cuda.is_current_stream_capturing():
+        return                             # inside a HIP graph capture nothing may synchronise: a replay's bit shows at check_status()
     if _CHECK_MODE == "sync":
         if int(ent[0].item()) != 0:      # synchronises the stream
             _raise_flagged(ent)

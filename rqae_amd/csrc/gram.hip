@@ -224,7 +224,7 @@ __device__ __forceinline__ void glds16(const void *gsrc_lane, void *lds_wave_bas
 // ------------------------------------------------------------------------------------------------ pack kernels
 // W_in image: fragment (ks, u, part) = 1 KiB = A operand of v_mfma_f32_16x16x32_bf16: lane 16g+r holds row r
 // (output 16u+r), k = 8g+j (element 32ks+8g+j).
-__global__ void gram_pack_win_kernel(Geom g, const float *w_in, uint16_t *img)
+__global__ void gram_pack_win_kernel(Geom g, const float *w_in, const float *in_scale, uint16_t *img)
 {
     const size_t total = (size_t)g.KSA * g.NOG * 3 * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -236,7 +236,10 @@ __global__ void gram_pack_win_kernel(Geom g, const float *w_in, uint16_t *img)
         const int o = 16 * u + (lane & 15), e = 32 * ks + 8 * (lane >> 4) + j;
         const int lg = o / g.GP, rem = o % g.GP, li = rem / g.CP, jj = rem % g.CP, l = lg * g.GL + li;
         float v = 0.0f;
-        if (rem < g.GL * g.CP && l < g.L && jj < g.c) v = w_in[((size_t)l * g.c + jj) * g.d + e];
+        if (rem < g.GL * g.CP && l < g.L && jj < g.c) {
+            v = w_in[((size_t)l * g.c + jj) * g.d + e];
+            if (in_scale) v = v * in_scale[e];     // a diagonal map in front of lin_in (Gemma's 1 + w) folded into the image: one fp32 product
+        }
         img[i] = piece_of(v, part);
     }
 }
@@ -1246,6 +1249,7 @@ struct Tuning {
     int lev2;            // level chain of one level group: 2 = lean form (fp32 values to the reconstruction) with 16 waves per workgroup
                          // (default), 1 = lean form with 8 waves, 0 = first form
 };
+constexpr size_t LEV_STAMP_BYTES = 1u << 20;   // tools builds (-DRQAE_LEV_TIMELINE): 16 stamps per wave of the level chain, behind the fused kernel's
 constexpr long long GRAM_CHUNK = 262144;   // tokens per pass: sizes the workspace (rqae_hip_gram_workspace_bytes), so not a per-call option
 
 Tuning default_tuning()
@@ -1349,7 +1353,7 @@ size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
     const long long tp = pad64(ch);
     // projections, TWO operand-row buffers (the pipelined schedule reconstructs pass i while pass i+1 fills the other one), dump
     // rows, timeline stamps (tools build)
-    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + 2 * al256(cv_row_bytes(g, levels) * tp) + 32768 + (2048 + 8 * 36 * 4) * 8;
+    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + 2 * al256(cv_row_bytes(g, levels) * tp) + 32768 + (2048 + 8 * 36 * 4) * 8 + LEV_STAMP_BYTES;
 }
 
 bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 + (size_t)g.GL * g.GL * g.GB * 4 <= 158 * 1024; }
@@ -1422,7 +1426,8 @@ size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_share
 }
 
 int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
-                       const float *codebook, const float *w_out, const float *b_out, int codebook_shared, void *stream)
+                       const float *codebook, const float *w_out, const float *b_out, int codebook_shared, const float *in_scale,
+                       void *stream)
 {
     if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared)) return gfail("gram_pack: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
     if (!packed || !w_in || !b_in || !codebook || !w_out || !b_out) return gfail("gram_pack: null pointer");
@@ -1435,7 +1440,7 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
     h.magic = GRAM_MAGIC; h.d = d; h.c = c; h.K = K; h.L = L; h.shared_cb = g.shared_cb;
     G_TRY(hipMemcpyAsync(b, &h, sizeof(h), hipMemcpyHostToDevice, s));
     G_TRY(hipMemsetAsync(b + lo.kconst, 0, sizeof(float) * (size_t)g.NOG * 16, s));
-    hipLaunchKernelGGL(gram_pack_win_kernel, dim3(2048), dim3(256), 0, s, g, w_in, reinterpret_cast<uint16_t *>(b + lo.win_img));
+    hipLaunchKernelGGL(gram_pack_win_kernel, dim3(2048), dim3(256), 0, s, g, w_in, in_scale, reinterpret_cast<uint16_t *>(b + lo.win_img));
     G_TRY(hipGetLastError());
     hipLaunchKernelGGL(gram_pack_gram_kernel, dim3((unsigned)L, (unsigned)L + 1), dim3(256), 0, s, g, w_in, b_in, w_out, b_out,
                        reinterpret_cast<float *>(b + lo.gneg), reinterpret_cast<float *>(b + lo.kconst));
@@ -1467,7 +1472,7 @@ namespace {
 // chunk (rqae_hip_encode_gram_phases)
 int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
                      int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, const rqae_hip_gram_options *opts,
-                     void *stream, hipEvent_t *ev)
+                     void *stream, hipEvent_t *ev, float *inv_rms = nullptr, float eps = 0.0f)
 {
     Tuning tun;
     if (int rc = make_tuning(opts, tun)) return rc;
@@ -1496,7 +1501,9 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     unsigned *cvimg2 = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(cvimg) + al256(cv_row_bytes(g, levels) * tp));
     float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg2) + al256(cv_row_bytes(g, levels) * tp));
 
-    if (tuning().fused && x_dtype != RQAE_X_F32 && fused_shape_ok(g, levels)) {
+    if (inv_rms && !(tuning().proj == 3 && x_dtype != RQAE_X_F32 && d % 64 == 0))
+        return gfail("encode_gram_gemma: the folded norm is served for bf16 / fp16 hidden states with d %% 64 == 0 (d=%d, x_dtype=%d)", d, x_dtype);
+    if (!inv_rms && tuning().fused && x_dtype != RQAE_X_F32 && fused_shape_ok(g, levels)) {
         FusedParams pf;
         pf.x = x; pf.win_img = v.win_img; pf.kconst = v.kconst; pf.gneg = v.gneg; pf.cb_img = v.cb_img; pf.cb_f32 = v.cb_f32;
         pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = q_out;
@@ -1570,6 +1577,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                 pf.ny = 1;
             }
             pf.ug0 = 0;
+            pf.inv_rms = inv_rms ? inv_rms + t0 : nullptr;
+            pf.eps = eps;
             auto go = [&](auto kern) -> int {
                 G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pf);
@@ -1577,7 +1586,10 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                 return 0;
             };
             int rc;
-            if (g.CP == 4) rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 4, true, 1>);
+            if (inv_rms) {     // Gemma's RMSNorm folded into the projection (MODE 5)
+                if (g.CP == 4) rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 5>) : go(gram_fused_kernel<RQAE_X_F16, 4, true, 5>);
+                else rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 5, true, 5>) : go(gram_fused_kernel<RQAE_X_F16, 5, true, 5>);
+            } else if (g.CP == 4) rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 4, true, 1>);
             else rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 5, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 5, true, 1>);
             if (rc) return rc;
         } else if (tuning().proj >= 2 && g.KSA % 4 == 0) {
@@ -1632,6 +1644,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pl.cvf = reinterpret_cast<float *>(cvimg); pl.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pl.n_tokens = nt; pl.tok_pad = tp; pl.ntiles = (nt + 63) / 64;
             pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c;
+            pl.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768 + (2048 + 8 * 36 * 4) * 8);
             // 16 waves per workgroup (four per SIMD: one wave's serial part behind the others' scans) where the tables leave room
             const int nw = (tuning().lev2 == 2 && c == g.CP && lev2_lds_bytes(c, K, 16) <= 160 * 1024) ? 16 : F_NW;
             const size_t lds = lev2_lds_bytes(c, K, nw);
@@ -1804,6 +1817,24 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
 {
     return encode_gram_impl(packed, d, c, K, L, codebook_shared, x, x_dtype, n_tokens, levels, q_out, indices, workspace, options,
                             stream, nullptr);
+}
+
+// RQAE.hook's `norm` + forward for a Gemma-2 model (rqae/model.py:279-281, rqae/llm.py:65-66) on the matrix-core arm: x is the
+// hooked layer's output itself; the packed block must have been built with in_scale = 1 + norm.weight.
+int rqae_hip_encode_gram_gemma_supported(int d, int c, int K, int L, int codebook_shared, int x_dtype)
+{
+    return rqae_hip_gram_supported(d, c, K, L, codebook_shared) && d % 64 == 0 && (x_dtype == RQAE_X_BF16 || x_dtype == RQAE_X_F16) ? 1 : 0;
+}
+
+int rqae_hip_encode_gram_gemma(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *hs, int hs_dtype,
+                               float eps, int64_t n_tokens, int levels, float *q_out, int64_t *indices, float *inv_rms,
+                               void *workspace, const rqae_hip_gram_options *options, void *stream)
+{
+    if (!inv_rms) return gfail("encode_gram_gemma: inv_rms is NULL");
+    if (!rqae_hip_encode_gram_gemma_supported(d, c, K, L, codebook_shared, hs_dtype))
+        return gfail("encode_gram_gemma: unsupported shape / dtype d=%d c=%d K=%d L=%d hs_dtype=%d", d, c, K, L, hs_dtype);
+    return encode_gram_impl(packed, d, c, K, L, codebook_shared, hs, hs_dtype, n_tokens, levels, q_out, indices, workspace, options,
+                            stream, nullptr, inv_rms, eps);
 }
 
 // RQAE.decode on the matrix-core arm: out = sum_l (W_out[l] codebook[idx_l] + b_out[l]) as the reconstruction kernel computes it

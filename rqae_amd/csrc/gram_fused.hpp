@@ -49,6 +49,8 @@ struct FusedParams {
     const float *cvf;          // MODE 3: fp32 straight-through values, level planes [8][tok_pad][CP]
     const void *codes;         // MODE 4: code indices [n_tokens][levels] (int64 / int32 / uint16 by the XT parameter: RQAE_IDX_*)
     int *status;               // MODE 4: include/rqae_hip.h "Status word" (a code outside -K..K-1), or NULL
+    float *inv_rms;            // MODE 5: 1 / sqrt(mean(x^2) + eps) per token, written for the way back (rqae_hip_gemma_denorm_patch)
+    float eps;                 // MODE 5
 };
 
 constexpr int F_NW = 8;                 // waves per workgroup
@@ -133,12 +135,17 @@ __device__ __forceinline__ void wave_sync_lds()
 // MODE 0: all three phases.  MODE 1: phase A alone (projections to global memory: the first kernel of the three-kernel
 // path).  MODE 4: phase C alone from code indices (decode; XT then names the index type).  MODE 2 / 3: phase C alone (its third kernel; operand rows as bf16 pieces from gram_levels_kernel / as fp32 values from
 // gram_levels2_kernel).  Same code, same bits.
+// MODE 5: MODE 1 with Gemma's RMSNorm folded in (rqae/llm.py:65-66 in front of forward, rqae/model.py:279-281): the norm is
+// linear in front of lin_in -- normed = (x rs) (1 + w) with rs = 1 / sqrt(mean(x^2) + eps) per token -- so (1 + w) is folded into
+// the W_in image at pack time (rqae_hip_gram_pack's in_scale), the kernel sums x^2 while the tile's fragments pass through its
+// registers (v_dot2c_f32_bf16 / _f16, four per fragment) and scales the projections by rs before they leave; `normed` never exists.
 template <int XT, int CP, bool CEQ, int MODE = 0>
 __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
 {
     using G = FusedGeom<CP>;
     constexpr int GL = G::GL, NG = G::NG, NKS = G::NKS, GB = G::GB, KC = G::KC, STAGE_A = G::STAGE_A, STAGE_C = G::STAGE_C;
-    static_assert(MODE >= 2 || XRaw<XT>::ESZ == 2, "x rows are staged as 128-byte pieces of 64 two-byte elements");
+    constexpr bool PROJ = MODE == 1 || MODE == 5, NORM = MODE == 5;
+    static_assert((MODE >= 2 && !PROJ) || XRaw<XT>::ESZ == 2, "x rows are staged as 128-byte pieces of 64 two-byte elements");
     constexpr int FPK = NG * 3;                    // W_in fragments per k-step
     constexpr int XP = 4;                          // x pieces per chunk and wave (32 rows x 128 bytes)
     static_assert(A_TT == 2, "32 tokens per wave");
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
     long long Gn = gridDim.x, tile_first = blockIdx.x;
     int ug0 = p.ug0;
     bool x_shared = false;
-    if constexpr (MODE == 1) {
+    if constexpr (PROJ) {
         if (p.ny > 1) {
             // XCD-aware mapping: consecutive workgroup ids go round the 8 XCDs, so ids that are equal mod 8 share an L2.  The ny
             // workgroups that take the same token tile through different output groups get such ids and run at the same time:
@@ -203,7 +210,8 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
         for (int u = 0; u < NG; ++u)
 #pragma unroll
             for (int T = 0; T < A_TT; ++T) acc[u][T] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE < 2) {
+        float ssq[A_TT] = {0.0f, 0.0f};          // NORM: this lane's share of sum(x^2) of its token in each token tile
+        if constexpr (MODE < 2 || PROJ) {
             // Piece pc of a chunk = rows 8 pc .. 8 pc + 7 of the wave x 128 bytes; lane i = (row r = i >> 3, slot jj = i & 7)
             // lands at piece + 16 i and fetches the row's 16-byte chunk jj ^ r: LDS row r holds chunk j at slot j ^ r, and the
             // operand reads below (lane (g, n): row n, chunk 4k + g) touch 16 different bank groups per 16-lane read group.
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                     const int ks = cc * KC + k;          // < KSA: the host sends only d % (32 KC) == 0 here
 #endif
                     int fu = f / 3;                      // groups past the last one repeat it (MODE 1, never stored)
-                    fu = (MODE == 1 ? ug0 : 0) + fu;
+                    fu = (PROJ ? ug0 : 0) + fu;
                     fu = fu < p.NOG ? fu : p.NOG - 1;
                     dma_piece(uniform_ptr(p.win_img + (((size_t)ks * p.NOG + fu) * 3 + (f % 3)) * 512), lds0 + slot * STAGE_A + (k * FPK + f) * 1024, lane16);
                 }
@@ -272,6 +280,23 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                     for (int k = 0; k < KC; ++k)
 #pragma unroll
                         for (int T = 0; T < A_TT; ++T) xraw[k][T][0] = *reinterpret_cast<const u32x4 *>(xs + xro[T][k]);
+                    if constexpr (NORM) {
+#pragma unroll
+                        for (int k = 0; k < KC; ++k)
+#pragma unroll
+                            for (int T = 0; T < A_TT; ++T)
+#pragma unroll
+                                for (int wd = 0; wd < 4; ++wd) {
+                                    const unsigned u = xraw[k][T][0][wd];
+                                    if constexpr (XT == RQAE_X_BF16) {
+                                        typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+                                        ssq[T] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, u), __builtin_bit_cast(bf2, u), ssq[T], false);
+                                    } else {
+                                        typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
+                                        ssq[T] = __builtin_amdgcn_fdot2(__builtin_bit_cast(hf2, u), __builtin_bit_cast(hf2, u), ssq[T], false);
+                                    }
+                                }
+                    }
                     u32x4 fr[NF];
 #pragma unroll
                     for (int i = 0; i < NF; ++i) fr[i] = *reinterpret_cast<const u32x4 *>(wb + i * 1024);
@@ -303,8 +328,22 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated groups past the last chunk
         }
         F_STAMP(1);
-        if constexpr (MODE == 1) {
+        if constexpr (PROJ) {
             // D layout: lane (g, n) holds outputs 4g..4g+3 of token 16T+n of group u
+            if constexpr (NORM) {
+                // the four lanes (g) of a token hold a quarter of its squares each; every one of them ends up with the row's sum
+#pragma unroll
+                for (int T = 0; T < A_TT; ++T) {
+                    float v = ssq[T];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    const float rs = 1.0f / __builtin_sqrtf(v / (float)p.d + p.eps);
+                    const long long tok = tw0 + 16 * T + n;
+                    if (g == 0 && tok < tile_end && ug0 == p.ug0) p.inv_rms[tok] = rs;
+#pragma unroll
+                    for (int u = 0; u < NG; ++u) acc[u][T] = f32x4{acc[u][T][0] * rs, acc[u][T][1] * rs, acc[u][T][2] * rs, acc[u][T][3] * rs};
+                }
+            }
 #pragma unroll
             for (int u = 0; u < NG; ++u)
 #pragma unroll
@@ -833,7 +872,16 @@ struct Lev2Params {
     long long *idx;            // [n_tokens][levels]
     long long n_tokens, tok_pad, ntiles;
     int levels, L, K, KTP, c;
+    unsigned long long *stamps;   // tools build (-DRQAE_LEV_TIMELINE) only: 16 s_memtime / s_memrealtime stamps per wave
 };
+
+#ifdef RQAE_LEV_TIMELINE
+#define L_STAMP(i) do { if (lane == 0) p.stamps[((size_t)blockIdx.x * NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define L_STAMPR(i) do { if (lane == 0) p.stamps[((size_t)blockIdx.x * NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define L_STAMP(i) do { } while (0)
+#define L_STAMPR(i) do { } while (0)
+#endif
 
 __host__ __device__ inline size_t lev2_lds_bytes(int c, int K, int nw = F_NW)
 {
@@ -851,6 +899,8 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
     const int c = CEQ ? CP : p.c;
     const int levels = p.levels;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    L_STAMP(0);
+    L_STAMPR(12);
     char *cbl = smem;
     const unsigned off_cbf = (unsigned)p.KTP * 1024u;
     const unsigned cbf_bytes = (unsigned)pad1k(((size_t)p.K + 64) * c * 4);
@@ -871,6 +921,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    L_STAMP(1);
     const int wq = (lane >> 2) & 3;
     const int ngrp = p.KTP / 4;
     const bool kragged = (p.K & 15) != 0;
@@ -895,6 +946,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) Q[li][j] = buf[li * CP + j];
         }
+        L_STAMP(2);
         constexpr bool EARLY = NW > 8;           // 16 waves: 128 registers per lane -- the values leave level by level instead of at the end
         float cvh[EARLY ? 1 : GL][CP];
         int codes[GL];
@@ -1115,6 +1167,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                             for (int i = 0; i < CP; ++i) Q[li2][j] = __builtin_fmaf(gbr[cur][j * CP + i], cvh[EARLY ? 0 : li][i], Q[li2][j]);
                     }
                 }
+                L_STAMP(3 + li);
             } else {
                 codes[li] = 0;
                 if constexpr (EARLY) {
@@ -1141,5 +1194,13 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                 for (int j = 0; j < CP; ++j) dst[j] = cvh[li][j];
             }
         }
+        L_STAMP(11);
+        L_STAMPR(13);
+#ifdef RQAE_LEV_TIMELINE
+        if (lane == 0) {
+            p.stamps[((size_t)blockIdx.x * NW + wave) * 16 + 14] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID
+            p.stamps[((size_t)blockIdx.x * NW + wave) * 16 + 15] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+        }
+#endif
     }
 }

@@ -128,6 +128,7 @@ class RQAE(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         self._packed = None  # .to()/.cuda()/.float() move or retype the parameters
         self._gram = None
+        self.__dict__.pop("_gram_scaled", None)
         self._gram_ws = None
         self._drop_metadata_cache()
         return super()._apply(fn, *args, **kwargs)
@@ -135,6 +136,7 @@ class RQAE(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         self._packed = None
         self._gram = None
+        self.__dict__.pop("_gram_scaled", None)
         self._drop_metadata_cache()
         return super().load_state_dict(*args, **kwargs)
 
@@ -150,6 +152,7 @@ class RQAE(nn.Module):
         state["_packed_key"] = None
         state["_gram"] = None
         state["_gram_ws"] = None
+        state.pop("_gram_scaled", None)
         state["gram_options"] = None      # a ctypes struct: not picklable, and a per-process tuning choice anyway
         state.pop("_param_list", None)
         state.pop("_key_state", None)
@@ -211,6 +214,7 @@ class RQAE(nn.Module):
         """Drop the packed parameter blocks (call after a ``.data`` write that the version counters cannot see)."""
         self._packed = None
         self._gram = None
+        self.__dict__.pop("_gram_scaled", None)
         self.__dict__.pop("_param_list", None)
         self.__dict__.pop("_key_state", None)
 
@@ -295,6 +299,22 @@ class RQAE(nn.Module):
                     raise RuntimeError("rqae_amd: the matrix-core arm needs one codebook shared by all levels")
                 self._gram = (key, _native.gram_pack(w_in, b_in, cb, w_out, b_out, True))
         return self._gram[1]
+
+    def gram_packed_weights_scaled(self, norm_weight: torch.Tensor) -> torch.Tensor:
+        """The matrix-core arm's block with Gemma's ``1 + norm.weight`` folded into the ``W_in`` image (include/rqae_hip.h:
+        rqae_hip_gram_pack's in_scale), for ``rqae_hip_encode_gram_gemma``; cached per (parameters, norm weight)."""
+        key = (self._weights_key(), norm_weight.data_ptr(), norm_weight._version)
+        ent = self.__dict__.get("_gram_scaled")
+        if ent is None or ent[0] != key or ent[2] is not norm_weight:
+            with torch.no_grad():
+                w_in, b_in, w_out, b_out = self._stacked()
+                cb = self.codebook.detach().float().contiguous()
+                if not bool((cb == cb[:1]).all()):
+                    raise RuntimeError("rqae_amd: the matrix-core arm needs one codebook shared by all levels")
+                scale = 1.0 + norm_weight.detach().float()
+                ent = (key, _native.gram_pack(w_in, b_in, cb, w_out, b_out, True, in_scale=scale), norm_weight)
+            self.__dict__["_gram_scaled"] = ent
+        return ent[1]
 
     def _encode_gram(self, x2d, levels, want_recon):
         need = _native.gram_workspace_bytes(self._dims(), x2d.shape[0], levels)
@@ -587,7 +607,20 @@ class RQAE(nn.Module):
             fold = (store is None and hs_llm.shape[-1] == self._dim and self.quantization_method in _FSQ_METHODS
                     and n_tok > 8 * torch.cuda.get_device_properties(hs_llm.device).multi_processor_count
                     and _native.encode_gemma_supported(self._dims()))
-            if fold:
+            fold_gram = (store is None and hs_llm.shape[-1] == self._dim and self._use_gram(n_tok, self.num_quantizers)
+                         and _native.encode_gram_gemma_supported(self._dims(), hs_llm.dtype))
+            if fold_gram:
+                # the matrix-core arm (self.arm = "gram" / "auto"): 1 + w folded into the W_in image, sum(hs^2) taken in the
+                # projection kernel, projections scaled by 1/rms -- Tier-2 parity like every call on this arm
+                need = _native.gram_workspace_bytes(self._dims(), n_tok, self.num_quantizers)
+                ws = self._gram_ws
+                if ws is None or ws.device != hs_llm.device or ws.numel() < need:
+                    ws = self._gram_ws = torch.empty(need, dtype=torch.uint8, device=hs_llm.device)
+                q_out, codes, inv_rms = _native.encode_gram_gemma(self.gram_packed_weights_scaled(final_norm.weight), self._dims(),
+                                                                  hs_llm, eps, self.num_quantizers, workspace=ws,
+                                                                  options=self.__dict__.get("gram_options"))
+                self.update_codebook_counts(codes)
+            elif fold:
                 # nobody asked for `normed`: the norm runs inside the encode kernel's load (same bits)
                 q_out, codes, inv_rms = _native.encode_gemma(self.packed_weights(), self._dims(), hs_llm,
                                                              final_norm.weight, eps, self.num_quantizers)

@@ -453,6 +453,89 @@ def test_operators_match_the_module_bit_for_bit():
         assert torch.equal(cv, cv2) and torch.equal(k, k2)
 
 
+class _Gemma2RMSNorm(torch.nn.Module):
+    """HF Gemma2RMSNorm, the module behind Gemma2.norm (rqae/llm.py:65-66)."""
+
+    def __init__(self, weight, eps=1e-6):
+        super().__init__()
+        self.weight = torch.nn.Parameter(weight)
+        self.eps = eps
+
+    def forward(self, x):
+        out = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + self.eps)
+        return (out * (1.0 + self.weight.float())).type_as(x)
+
+
+class _FakeGemma2LLM:
+    """Shaped like rqae/llm.py:Gemma2: .model.model.norm plus norm()/denorm()."""
+
+    def __init__(self, weight):
+        inner = torch.nn.Module()
+        inner.norm = _Gemma2RMSNorm(weight)
+        outer = torch.nn.Module()
+        outer.model = inner
+        self.model = outer
+
+    def norm(self, hidden_states):
+        return self.model.model.norm(hidden_states)
+
+    def denorm(self, hidden_states, original_hidden_states):
+        hidden_states = hidden_states / (1.0 + self.model.model.norm.weight.float())
+        return hidden_states.float() / torch.rsqrt(original_hidden_states.float().pow(2).mean(-1, keepdim=True) + 1e-6)
+
+
+@pytest.mark.parametrize("dtype,B,S", [(torch.float16, 4, 128), (torch.bfloat16, 3, 77), (torch.float16, 160, 128), (torch.bfloat16, 1, 1)])
+def test_gemma_hook_on_the_matrix_core_arm(dtype, B, S):
+    """SURVEY 8(f1) on the fast arm: RQAE.hook(llm=gemma) with arm='gram' folds 1 + w into the W_in image, takes sum(hs^2) inside
+    the projection kernel (rqae_hip_encode_gram_gemma) and scales the projections by 1/rms (rqae/model.py:276-289,
+    rqae/llm.py:65-73).  Against the oracle on the canonically normed rows: Tier 2 for the codes; the patched layer output
+    against the exact arm's fused hook (bit-equal to the oracle's restatement: test_hip_parity.py) to fp16 / bf16 rounding."""
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    mg_, me_ = make_model(cfg, w, "gram"), make_model(cfg, w, "exact")
+    d = cfg["dim"]
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + S))
+    nw = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    llm = _FakeGemma2LLM(torch.from_numpy(nw).to(DEV))
+    n = B * S
+    hs0 = (torch.from_numpy(np.concatenate([synth.activations(500 + i, min(8192, n - s), d) for i, s in enumerate(range(0, n, 8192))])) * 3.0)
+    hs0 = hs0.to(dtype).view(B, S, d).to(DEV)
+    seen = {}
+
+    def run(m, with_store):
+        hs = hs0.clone()
+        st = {}
+        kw = dict(store=lambda k, v: st.update({k: v})) if with_store else {}
+        with torch.inference_mode():
+            m.hook(llm=llm, **kw)(None, None, (hs,))
+        torch.cuda.synchronize()
+        return hs, st
+
+    hs_g, _ = run(mg_, False)                      # no store: the folded path (rqae_hip_encode_gram_gemma)
+    hs_e, st_e = run(me_, True)                    # exact arm, with the store: normed / indices / quantized / new
+    # the codes of the folded call: take them from a direct call of the entry point (the hook keeps none without a store)
+    q_g, idx_g, rs_g = _native.encode_gram_gemma(mg_.gram_packed_weights_scaled(llm.model.model.norm.weight), mg_._dims(), hs0, 1e-6, 8)
+    torch.cuda.synchronize()
+    hs_np = hs0.float().cpu().numpy().reshape(n, d)
+    normed_o, rs_o = oracle.gemma_norm_canonical(hs_np.reshape(B, S, d), nw)
+    listed = check_tier2(normed_o.reshape(n, d), w, q_g.cpu().numpy().reshape(n, d), idx_g.cpu().numpy().reshape(n, -1))
+    assert np.abs(rs_g.cpu().numpy().reshape(-1) / np.asarray(rs_o).reshape(-1) - 1).max() < 2e-6
+    assert listed <= max(2, n // 20000)
+    # the patched output: BOS rows untouched, every other row within rounding of the exact arm's on tokens with the same codes
+    assert torch.equal(hs_g[:, 0], hs0[:, 0])
+    same = (idx_g == st_e["indices"]).all(-1)
+    a, b = hs_g.float()[same], hs_e.float()[same]
+    if a.numel():
+        scale = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+        assert float(((a - b).abs() / scale).max()) <= ulp                       # at most one rounding step of the LLM dtype
+        assert float((a != b).float().mean()) < 0.02                             # and nearly every element identical
+    # with a store the hook takes the norm as its own kernel + forward on the matrix-core arm: same protocol, same codes
+    hs_s, st_s = run(mg_, True)
+    assert set(st_s) == {"original", "normed", "quantized", "indices", "new"}
+    assert (st_s["indices"] == idx_g).all(-1).float().mean().item() > 0.999
+
+
 def test_operators_see_weights_restacked_after_an_update():
     """stack, encode, modify the per-level weights in place, re-stack, encode -- the second call must use the
     new weights (compared with a model loaded from them), also when the new stack reuses the old one's address; same for the

@@ -67,7 +67,7 @@ __device__ __forceinline__ void static_for(F &&f)
 
 constexpr int GRAM_MAGIC = 0x4752414d;  // "GRAM"
 constexpr int GRAM_MAX_L = 64;
-constexpr int GRAM_MAX_C = 5;           // instantiated: CP = 4, 5
+constexpr int GRAM_MAX_C = 13;          // instantiated: CP = 4, 5 (resident / streamed codebook), 13 (gram_wide.hpp: 6 <= c <= 13)
 
 // ------------------------------------------------------------------------------------------------ geometry
 // CP   padded codebook_dim the kernels are instantiated for (c <= CP, padding is zero weights)
@@ -79,7 +79,7 @@ struct Geom {
     int d, c, K, L, CP, GL, GP, GS, NLG, NOG, KSA, NKC, KT, KTP, NET, NKSC, GB, shared_cb;
 };
 
-__host__ __device__ inline int cp_of(int c) { return c <= 4 ? 4 : 5; }
+__host__ __device__ inline int cp_of(int c) { return c <= 4 ? 4 : c == 5 ? 5 : 13; }
 __host__ __device__ inline int gl_of(int CP) { return CP <= 8 ? 8 : 4; }
 
 __host__ __device__ inline Geom make_geom(int d, int c, int K, int L, int shared_cb)
@@ -1230,6 +1230,7 @@ __global__ __launch_bounds__(NW * 64) void gram_reconstruct_kernel(RecParams p)
 
 #include "gram_fused.hpp"
 #include "gram_stream.hpp"
+#include "gram_wide.hpp"
 
 constexpr int B_NW = 8;
 
@@ -1361,10 +1362,13 @@ bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g
 // a codebook too large for LDS streams through it (gram_stream.hpp): one shared codebook, one k-step per cosine contraction
 bool levels_stream_ok(const Geom &g) { return g.shared_cb && g.NKC == 1 && g.CP <= 5; }
 
+// wide codebook vectors (6 <= c <= 13: three k-steps per cosine contraction, four levels per group): gram_wide.hpp
+bool levels_wide_ok(const Geom &g) { return g.shared_cb && g.CP == 13 && g.NKC == 3 && g.d % 128 == 0 && g.NLG <= 4; }
+
 // the one-kernel form: one level group, whole chunks of 2 k-steps, everything resident fits the CU's 160 KiB of LDS
 bool fused_shape_ok(const Geom &g, int levels)
 {
-    return g.shared_cb && levels <= 8 && g.d % 64 == 0 && g.NKC == 1 && fused_lds_bytes(g.d, g.c, g.K) <= 160 * 1024;
+    return g.shared_cb && g.CP <= 5 && levels <= 8 && g.d % 64 == 0 && g.NKC == 1 && fused_lds_bytes(g.d, g.c, g.K) <= 160 * 1024;
 }
 
 // Second stream for the pipelined schedule (encode_gram_impl): the reconstruction of pass i runs there, beside the projection
@@ -1406,6 +1410,7 @@ int recon_nks_template(int nks)
 
 }  // namespace
 
+#ifndef RQAE_GRAM_NO_ABI   /* tools/quick_isa.py compiles the kernels it names without the launch code below (which instantiates every kernel) */
 // ==================================================================================================== C ABI
 extern "C" {
 
@@ -1413,7 +1418,7 @@ int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared)
 {
     if (!gram_shape_ok(d, c, K, L)) return 0;
     const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
-    return (levels_resident_ok(g) || levels_stream_ok(g)) ? 1 : 0;
+    return ((g.CP <= 5 && levels_resident_ok(g)) || levels_stream_ok(g) || levels_wide_ok(g)) ? 1 : 0;
 }
 
 size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared)
@@ -1490,7 +1495,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     const Geom &g = v.g;
     const int nks = nks_recon(g, levels);
     const int nks_t = recon_nks_template(nks);
-    if (q_out && !nks_t) return gfail("encode_gram: reconstruction with %d k-steps is not instantiated (codes only: pass q_out = NULL)", nks);
+    const bool wide = g.CP == 13;
+    if (q_out && !nks_t && !wide) return gfail("encode_gram: reconstruction with %d k-steps is not instantiated (codes only: pass q_out = NULL)", nks);
     const size_t xs = x_dtype == RQAE_X_F32 ? 4 : 2;
     const int ncu = device_cus();
 
@@ -1501,7 +1507,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     unsigned *cvimg2 = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(cvimg) + al256(cv_row_bytes(g, levels) * tp));
     float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg2) + al256(cv_row_bytes(g, levels) * tp));
 
-    if (inv_rms && !(tuning().proj == 3 && x_dtype != RQAE_X_F32 && d % 64 == 0))
+    if (inv_rms && !(tuning().proj == 3 && g.CP <= 5 && x_dtype != RQAE_X_F32 && d % 64 == 0))
         return gfail("encode_gram_gemma: the folded norm is served for bf16 / fp16 hidden states with d %% 64 == 0 (d=%d, x_dtype=%d)", d, x_dtype);
     if (!inv_rms && tuning().fused && x_dtype != RQAE_X_F32 && fused_shape_ok(g, levels)) {
         FusedParams pf;
@@ -1542,10 +1548,10 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
 #else
     // one pass = projection + level chain (phaseAB) and reconstruction (phaseC) of the tokens [t0, t0 + nt); `ncu` caps the
     // persistent grids, `cvimg` is the operand-row buffer the two halves share
-    const bool recon2_ok = tuning().recon == 2 && levels <= 8 && d % 16 == 0 &&
+    const bool recon2_ok = tuning().recon == 2 && g.CP <= 5 && levels <= 8 && d % 16 == 0 &&
         pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW <= 160 * 1024;
     // one level group: the lean level chain hands fp32 straight-through values to the reconstruction (which splits them)
-    const bool lev2 = tuning().lev2 && levels <= 8 && g.shared_cb && g.NKC == 1 && lev2_lds_bytes(c, K) <= 160 * 1024 && (!q_out || recon2_ok);
+    const bool lev2 = tuning().lev2 && g.CP <= 5 && levels <= 8 && g.shared_cb && g.NKC == 1 && lev2_lds_bytes(c, K) <= 160 * 1024 && (!q_out || recon2_ok);
     auto phaseAB = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark, bool strict) -> int {
         if (mark) G_TRY(hipEventRecord(ev[0], s));
         // ---- A
@@ -1554,7 +1560,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pa.win_img = v.win_img; pa.P = P; pa.dump = dump; pa.n_tokens = nt; pa.tok_pad = tp; pa.d = d; pa.NOG = g.NOG; pa.KSA = g.KSA;
         // the LDS-DMA projection covers 3 (c = 5) or 2 (c <= 4) output groups per workgroup; deeper shapes launch ny workgroups per token
         // tile, placed on one XCD so that the tile's x is read from HBM once (RQAE_GRAM_PROJ=2: the register-pipelined kernel instead)
-        if (tuning().proj == 3 && x_dtype != RQAE_X_F32 && d % 64 == 0) {
+        if (tuning().proj == 3 && g.CP <= 5 && x_dtype != RQAE_X_F32 && d % 64 == 0) {
             FusedParams pf;
             memset(&pf, 0, sizeof(pf));
             pf.x = pa.x; pf.win_img = v.win_img; pf.P = P; pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c;
@@ -1592,7 +1598,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             } else if (g.CP == 4) rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 4, true, 1>);
             else rc = x_dtype == RQAE_X_BF16 ? go(gram_fused_kernel<RQAE_X_BF16, 5, true, 1>) : go(gram_fused_kernel<RQAE_X_F16, 5, true, 1>);
             if (rc) return rc;
-        } else if (tuning().proj >= 2 && g.KSA % 4 == 0) {
+        } else if ((tuning().proj >= 2 || wide) && g.KSA % 4 == 0) {
             const unsigned ny = (unsigned)((g.NOG + 2) / 3);
             long long gx = (nt + A2_NW * 16 * A_TT - 1) / (A2_NW * 16 * A_TT);     // persistent: one workgroup per CU walks the tiles
             const long long cap = ncu / ny > 0 ? ncu / ny : 1;
@@ -1638,6 +1644,25 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         }
         if (mark) G_TRY(hipEventRecord(ev[1], s));
         // ---- B
+        if (wide) {
+            LevParams pb;
+            pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
+            pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
+            pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
+            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
+            // 4 waves per workgroup (one per SIMD) until the batch fills the chip twice over: 8 then halve the image's L2 -> LDS traffic
+            const int nw = (pb.ntiles + 7) / 8 >= 2LL * ncu ? 8 : 4;
+            const size_t lds = wide_levels_lds_bytes(g.NKC, nw);
+            long long nb = (pb.ntiles + nw - 1) / nw;
+            if (nb > ncu) nb = ncu;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nw * 64), lds, s, pb);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            return nw == 8 ? go(gram_levels_wide_kernel<13, 8>) : go(gram_levels_wide_kernel<13, 4>);
+        }
         if (lev2) {
             Lev2Params pl;
             pl.P = P; pl.kconst = v.kconst; pl.gneg = v.gneg; pl.cb_img = v.cb_img; pl.cb_f32 = v.cb_f32;
@@ -1709,7 +1734,28 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     auto phaseC = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark) -> int {
         if (mark) G_TRY(hipEventRecord(ev[2], s));
         // ---- C
-        if (q_out && recon2_ok) {
+        if (q_out && wide) {
+            RecWideParams pw;
+            pw.wout_img = v.wout_img; pw.bias = v.bias_prefix + (size_t)(levels - 1) * d; pw.cvf = reinterpret_cast<const float *>(cvimg);
+            pw.out = q_out + (size_t)t0 * d; pw.n_tokens = nt; pw.tok_pad = tp; pw.d = d; pw.NKSC = g.NKSC; pw.NET = g.NET; pw.levels = levels;
+            long long nb = (nt + 127) / 128;
+            if (nb > ncu) nb = ncu;
+            auto go = [&](auto kern, size_t lds) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), lds, s, pw);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            int rc;
+            switch (g.NLG) {
+            case 1: rc = go(gram_recon_wide_kernel<13, 1>, wide_recon_lds_bytes<13, 1>()); break;
+            case 2: rc = go(gram_recon_wide_kernel<13, 2>, wide_recon_lds_bytes<13, 2>()); break;
+            case 3: rc = go(gram_recon_wide_kernel<13, 3>, wide_recon_lds_bytes<13, 3>()); break;
+            case 4: rc = go(gram_recon_wide_kernel<13, 4>, wide_recon_lds_bytes<13, 4>()); break;
+            default: return gfail("encode_gram: wide reconstruction serves up to 16 levels");
+            }
+            if (rc) return rc;
+        } else if (q_out && recon2_ok) {
             FusedParams pf;
             memset(&pf, 0, sizeof(pf));
             pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = q_out + (size_t)t0 * d;
@@ -1823,7 +1869,7 @@ int rqae_hip_encode_gram(const void *packed, int d, int c, int K, int L, int cod
 // hooked layer's output itself; the packed block must have been built with in_scale = 1 + norm.weight.
 int rqae_hip_encode_gram_gemma_supported(int d, int c, int K, int L, int codebook_shared, int x_dtype)
 {
-    return rqae_hip_gram_supported(d, c, K, L, codebook_shared) && d % 64 == 0 && (x_dtype == RQAE_X_BF16 || x_dtype == RQAE_X_F16) ? 1 : 0;
+    return rqae_hip_gram_supported(d, c, K, L, codebook_shared) && cp_of(c) <= 5 && d % 64 == 0 && (x_dtype == RQAE_X_BF16 || x_dtype == RQAE_X_F16) ? 1 : 0;
 }
 
 int rqae_hip_encode_gram_gemma(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *hs, int hs_dtype,
@@ -1843,6 +1889,7 @@ int rqae_hip_decode_gram_supported(int d, int c, int K, int L, int codebook_shar
 {
     if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared) || levels < 1 || levels > L || levels > 8 || d % 16) return 0;
     const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
+    if (g.CP > 5) return 0;
     return pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW <= 160 * 1024 ? 1 : 0;
 }
 
@@ -1906,3 +1953,5 @@ int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, 
 }
 
 }  // extern "C"
+
+#endif  /* RQAE_GRAM_NO_ABI */

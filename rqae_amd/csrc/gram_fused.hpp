@@ -895,7 +895,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
 {
     constexpr int GL = 8, GP = ((GL * CP + 15) / 16) * 16, NG = GP / 16, GB = (CP * CP + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c = CEQ ? CP : p.c;
     const int levels = p.levels;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
@@ -922,7 +922,6 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
         __syncthreads();
     }
     L_STAMP(1);
-    const int wq = (lane >> 2) & 3;
     const int ngrp = p.KTP / 4;
     const bool kragged = (p.K & 15) != 0;
     for (long long tile = (long long)blockIdx.x * NW + wave; tile < p.ntiles; tile += (long long)gridDim.x * NW) {
@@ -947,12 +946,30 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                 for (int j = 0; j < CP; ++j) Q[li][j] = buf[li * CP + j];
         }
         L_STAMP(2);
-        constexpr bool EARLY = NW > 8;           // 16 waves: 128 registers per lane -- the values leave level by level instead of at the end
+        constexpr bool EARLY = NW > 8;
+        if constexpr (EARLY) {
+            // planes of the levels not run (max_layers < 8) are zeros for the reconstruction: written here, ahead of the chain (a
+            // store inside an unrolled level drags a spilled zero vector and its vmcnt waits through the levels that do run)
+#pragma unroll 1
+            for (int lz = levels; lz < GL; ++lz) {
+                float *dst = p.cvf + ((size_t)lz * p.tok_pad + t) * CP;
+#pragma unroll
+                for (int j = 0; j < CP; ++j) dst[j] = 0.0f;
+            }
+        }           // 16 waves: 128 registers per lane -- the values leave level by level instead of at the end
         float cvh[EARLY ? 1 : GL][CP];
         int codes[GL];
         static_for<0, GL>([&](auto li_c) {
             constexpr int li = decltype(li_c)::value;
             if (li < levels) {
+                // Lane-derived LDS addresses are recomputed in every level from an opaque copy of the lane id: as common
+                // subexpressions of the eight unrolled levels hipcc keeps them live across the whole chain -- at 128 registers
+                // that meant spills, and every reload of a spilled register is a vector-memory operation whose s_waitcnt also
+                // waits for the level's code and value stores (loads and stores share vmcnt): a store round trip per level on
+                // the critical path of every wave.
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int g = ln >> 4, n = ln & 15, wq = (ln >> 2) & 3;
                 float q[CP];
 #pragma unroll
                 for (int j = 0; j < CP; ++j) q[j] = Q[li][j];
@@ -960,8 +977,6 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
 #pragma unroll
                 for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
                 const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
-                float xn[CP];
-                unit_dir<CP>(q, c, xn);      // the reference's q / ||q|| (rqae/model.py:188): what the exact rescoring multiplies the rows by
                 {   // B operand rows of the wave's 64 tokens: 32 slots = 64 bytes per token
                     unsigned dw[16];
 #pragma unroll
@@ -977,7 +992,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
 #pragma unroll
                     for (int pc = 0; pc < 4; ++pc) {
                         const int pos = (pc + 2 * wq) & 3;   // bank-conflict-free placement of the four 16-byte pieces
-                        *reinterpret_cast<u32x4 *>(xch + lane * 64 + pos * 16) = u32x4{dw[4 * pc], dw[4 * pc + 1], dw[4 * pc + 2], dw[4 * pc + 3]};
+                        *reinterpret_cast<u32x4 *>(xch + ln * 64 + pos * 16) = u32x4{dw[4 * pc], dw[4 * pc + 1], dw[4 * pc + 2], dw[4 * pc + 3]};
                     }
                 }
                 wave_sync_lds();
@@ -999,7 +1014,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                 u32x4 fa[4], fb[4];
                 auto ldfrag = [&](u32x4 (&f)[4], int grp) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const u32x4 *>(cbl + (grp * 4 + i) * 1024 + lane * 16);
+                    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const u32x4 *>(cbl + (grp * 4 + i) * 1024 + ln * 16);
                 };
                 auto scan4 = [&](const u32x4 (&a)[4], int grp) {
                     float mx[4];
@@ -1042,9 +1057,11 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                     *reinterpret_cast<u32x2 *>(xch + ((16 * T + n) * 4 + g) * 8) = u32x2{u32_of(best[T]), (unsigned)bgrp[T]};
                 }
                 wave_sync_lds();
-                const u32x4 h0 = *reinterpret_cast<const u32x4 *>(xch + lane * 32);
-                const u32x4 h1 = *reinterpret_cast<const u32x4 *>(xch + lane * 32 + 16);
+                const u32x4 h0 = *reinterpret_cast<const u32x4 *>(xch + ln * 32);
+                const u32x4 h1 = *reinterpret_cast<const u32x4 *>(xch + ln * 32 + 16);
                 wave_sync_lds();
+                float xn[CP];
+                unit_dir<CP>(q, c, xn);      // the reference's q / ||q|| (rqae/model.py:188): what the exact rescoring multiplies the rows by
                 float bv = f32_of(h0[0]);
                 int bgr = (int)h0[1], bg = 0;
                 bool amb = false;
@@ -1170,11 +1187,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
                 L_STAMP(3 + li);
             } else {
                 codes[li] = 0;
-                if constexpr (EARLY) {
-                    float *dst = p.cvf + ((size_t)li * p.tok_pad + t) * CP;
-#pragma unroll
-                    for (int j = 0; j < CP; ++j) dst[j] = 0.0f;
-                } else {
+                if constexpr (!EARLY) {
 #pragma unroll
                     for (int j = 0; j < CP; ++j) cvh[li][j] = 0.0f;
                 }

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_stream_kernel(LevParams p
                         for (int r = 0; r < 4; ++r) {
                             float sc = 0.0f;
 #pragma unroll
-                            for (int j = 0; j < CP; ++j) sc = __builtin_fmaf(f[r * CP + j], q[j], sc);
+                            for (int j = 0; j < CP; ++j) sc = __builtin_fmaf(xn[j], f[r * CP + j], sc);
                             const bool up = (sc > bsc) && (r0 + r < p.K);
                             bsc = up ? sc : bsc;
                             brow = up ? r0 + r : brow;

@@ -258,6 +258,57 @@ def test_gram_c5_streamed_codebook_depth_32():
     print(f"gram arm, C5 depth 32, {n} tokens: {len(rows)} low-margin tokens differ from the exact arm, all adjudicated")
 
 
+def test_gram_c4_wide_codebook_depth_16():
+    """BASELINE configs[3] as stated: d 3584, c 13, K 8192 = 2^13, depth 16 on the matrix cores (csrc/gram_wide.hpp: three k-steps
+    per cosine contraction, the 1.5 MB codebook image streamed through LDS, four level groups of four levels, reconstruction with
+    40 k-steps).  The reference capture (tests/golden/fwd_c4: 512 tokens, depth 4) and the oracle on 1500 tokens (fp32 and bf16
+    inputs, a shallower call, ragged sizes), then 65 536 tokens at depth 16 against the exact arm with every differing token
+    adjudicated."""
+    g4 = load_golden("fwd_c4")
+    cfg_g, w_g, x_g = case_inputs(g4)
+    mg4 = make_model(cfg_g, w_g, "gram")
+    assert mg4._use_gram(x_g.shape[0], cfg_g["num_quantizers"])
+    q, idx, xs = run(mg4, x_g, torch.float32)
+    listed = check_tier2(xs, w_g, q, idx)
+    assert ((idx != g4["codes"].astype(np.int64)).any(axis=1)).sum() == listed
+    cfg = dict(synth.CONFIGS["C4"])
+    assert cfg["codebook_size"] ** cfg["codebook_dim"] == 8192 and cfg["num_quantizers"] == 16
+    w = synth.weights(444, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    x = synth.activations(41, 1500, cfg["dim"])
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        q, idx, xs = run(m, x, dt)
+        assert idx.shape == (1500, 16) and idx.max() < 8192
+        check_tier2(xs, w, q, idx)
+    for nn, ml in ((1, 16), (63, 7), (65, 16), (300, 13), (129, 4), (1000, 1)):
+        q, idx, xs = run(m, x[:nn], torch.float32, max_layers=ml)
+        check_tier2(xs, w, q, idx, levels=ml)
+        with torch.inference_mode():
+            only = m.encode(torch.from_numpy(x[:nn]).to(DEV).view(1, nn, -1), max_layers=ml)
+        assert np.array_equal(only.cpu().numpy().reshape(nn, -1), idx)
+    # a batch that fills the chip
+    me_ = make_model(cfg, w, "exact")
+    n = 65536
+    g = torch.Generator(device=DEV); g.manual_seed(10)
+    z = torch.randn(n, cfg["dim"], device=DEV, generator=g)
+    xb = (z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6))
+    with torch.inference_mode():
+        q, idx = m(xb.view(1, n, -1))
+        q2, idx2 = m(xb.view(1, n, -1))
+        assert torch.equal(idx, idx2) and torch.equal(q, q2)
+        qe, ie = me_(xb.view(1, n, -1))
+    bad = (idx[0] != ie[0]).any(dim=1)
+    rows = torch.nonzero(bad).flatten().cpu().numpy()
+    assert len(rows) <= n // 1000, f"{len(rows)} of {n} tokens differ from the exact arm"
+    same = ~bad
+    scale = qe[0][same].abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert float(((q[0][same] - qe[0][same]).abs() / scale).max()) < RTOL
+    sel = np.unique(np.concatenate([rows, np.arange(0, n, 517)]))
+    listed = check_tier2(xb[sel].float().cpu().numpy(), w, q[0][sel].cpu().numpy(), idx[0][sel].cpu().numpy())
+    assert listed == len(rows)
+    print(f"gram arm, C4 depth 16, {n} tokens: {len(rows)} low-margin tokens differ from the exact arm, all adjudicated")
+
+
 def test_gram_decode_matches_the_exact_decode():
     """RQAE.decode on the matrix-core arm (rqae_hip_decode_gram: the reconstruction kernel fed by the codes) against the exact
     arm's decode, which is the oracle's and the reference capture's bits (test_hip_parity.py::test_decode): within 1e-6 of the

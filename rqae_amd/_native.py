@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "librqae_hip.so")
+# RQAE_HIP_LIBRARY: another build of the same library (tools/: timeline and ablation builds); the product loads its own
+SO_PATH = os.environ.get("RQAE_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "librqae_hip.so")
 
 ABI_VERSION = 3
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2

@@ -489,7 +489,8 @@ __global__ __launch_bounds__(A_NW * 64) void gram_project_kernel(ProjParams p)
 #pragma unroll
                         for (int T = 0; T < A_TT; ++T)
 #pragma unroll
-                            for (int xq = 0; xq < XFrag<XT>::NP; ++xq) acc[u][pp][T] = mfma16(a, xp[T][xq], acc[u][pp][T]);
+                            for (int xq = 0; xq < XFrag<XT>::NP; ++xq)
+                                if (pp + xq <= 2) acc[u][pp][T] = mfma16(a, xp[T][xq], acc[u][pp][T]);   // the six largest of the nine piece products
                     }
                 }
             }
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(A2_NW * 64) void gram_project2_kernel(ProjParams p)
 #pragma unroll
                         for (int xq = 0; xq < XFrag<XT>::NP; ++xq) {
                             if (ABL & 1) { if (i < KC * A_TT) acc[u][pp][T] += __builtin_bit_cast(f32x4, xp[k][T][xq] ^ fr[i]); }
-                            else acc[u][pp][T] = mfma16(fr[i], xp[k][T][xq], acc[u][pp][T]);
+                            else if (pp + xq <= 2) acc[u][pp][T] = mfma16(fr[i], xp[k][T][xq], acc[u][pp][T]);   // W piece x x piece: the six largest of nine (mid*lo, lo*mid, lo*lo are below 2^-24 relative), as in the c-space contractions
                         }
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
@@ -1603,6 +1604,10 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             long long gx = (nt + A2_NW * 16 * A_TT - 1) / (A2_NW * 16 * A_TT);     // persistent: one workgroup per CU walks the tiles
             const long long cap = ncu / ny > 0 ? ncu / ny : 1;
             if (gx > cap) gx = cap;
+            // several output-group blocks per token tile (deep shapes): workgroup (bx, by) has the linear id bx + by gx, and ids that
+            // are equal mod 8 share an XCD -- with gx a multiple of 8 the ny workgroups of a tile walk it on ONE XCD at the same
+            // time, so its x comes from HBM once and from that L2 ny - 1 times (C4, bf16 x: 2.2 GB fetched for 0.47 GB of x before)
+            if (ny > 1 && gx >= 8) gx &= ~7LL;
             const dim3 grid((unsigned)gx, ny);
             auto go = [&](auto kern, int kc) -> int {
                 const size_t lds = (size_t)A2_NS * kc * 9 * 1024;
@@ -1651,13 +1656,17 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
             pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
             // 4 waves per workgroup (one per SIMD) until the batch fills the chip twice over: 8 then halve the image's L2 -> LDS traffic
+#ifdef W_FORCE_NW8   /* tools build: two waves per SIMD on half the CUs */
+            const int nw = 8;
+#else
             const int nw = (pb.ntiles + 7) / 8 >= 2LL * ncu ? 8 : 4;
+#endif
             const size_t lds = wide_levels_lds_bytes(g.NKC, nw);
             long long nb = (pb.ntiles + nw - 1) / nw;
             if (nb > ncu) nb = ncu;
             auto go = [&](auto kern) -> int {
                 G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nw * 64), lds, s, pb);
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3((nw + W_NWL) * 64), lds, s, pb);     // + the loader waves
                 G_TRY(hipGetLastError());
                 return 0;
             };
@@ -1954,4 +1963,10 @@ int rqae_hip_encode_gram_phases(const void *packed, int d, int c, int K, int L, 
 
 }  // extern "C"
 
+#ifdef W_TIMELINE
+extern "C" int rqae_hip_debug_wide_stamps(unsigned long long *host_out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wide_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 #endif  /* RQAE_GRAM_NO_ABI */

@@ -13,8 +13,19 @@
 //                             operands), the W_out image streams through an LDS ring one element tile (40 KiB) per stage
 // The projection is gram_project2_kernel (any number of output groups).  Tier-2 parity like the rest of the arm.
 
+#ifdef W_TIMELINE   /* tools build (tools/wide_timeline.py): per wave, cycles spent in the parts of the level chain */
+__device__ unsigned long long g_wide_stamps[8192 * 8];
+#define W_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define W_ACC(acc, a, b) acc += (unsigned)((b) - (a))
+#else
+#define W_T(var) do { } while (0)
+#define W_ACC(acc, a, b) do { } while (0)
+#endif
+
 constexpr int W_STT = 8;        // row tiles per ring stage
-constexpr int W_NST = 3;        // ring slots
+constexpr int W_NST = 5;        // ring slots: four stages in flight ahead of the one being multiplied
+constexpr int R_NST = 3;        // ring slots of the reconstruction (40 KiB each at C4)
+constexpr int W_NWL = 2;        // loader waves per workgroup of the level chain (four measured the same)
 
 template <int CP> struct WideGeom {
     static constexpr int GL = 4;                                   // levels per level group (gl_of)
@@ -27,16 +38,21 @@ template <int CP> struct WideGeom {
     static constexpr int CVS = 16;                                 // floats per token and level in the value planes (c <= 13, padded)
 };
 
-__host__ __device__ inline size_t wide_levels_lds_bytes(int nkc, int nw) { return (size_t)W_NST * W_STT * nkc * 1024 + (size_t)nw * 4096; }
+__host__ __device__ inline size_t wide_levels_lds_bytes(int nkc, int nw) { return (size_t)W_NST * W_STT * nkc * 1024 + (size_t)nw * 4096; }   // nw = computing waves
 
 // p.cvimg is used as float planes [levels][tok_pad][16]
+// (second launch bound: a budget of 256 registers, so the MFMA accumulators stay in VGPRs.  With the 512 registers one wave per SIMD
+//  may take, hipcc parks them in AGPRs and pays four v_accvgpr_read + s_nop per accumulator before the maxima can read them.)
+// Waves 0 .. NW-1 compute; waves NW, NW+1 only move the image: a global_load_lds occupies its wave's issue for 100-185 cycles
+// (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), and with one computing wave per SIMD a wave that waits there is an idle matrix
+// pipe -- measured: 41.5 cycles per matrix instruction with the pieces issued by the computing waves, 16.3 with no refill at all.
 template <int CP, int NW>
-__global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
+__global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(LevParams p)
 {
     using G = WideGeom<CP>;
     constexpr int GL = G::GL, GP = G::GP, NKC = G::NKC, GB = G::GB, STAGE = G::STAGE, CVS = G::CVS;
     static_assert(NKC == 3, "three k-steps per cosine contraction");
-    static_assert((W_STT * NKC) % NW == 0, "every wave issues the same number of pieces per stage");
+    static_assert((W_STT * NKC) % W_NWL == 0, "every loader wave issues the same number of pieces per stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
@@ -45,29 +61,76 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
     const float *cbf = p.cb_f32;                       // global (L2): K x c fp32, + 64 zero rows
     float *cvf = reinterpret_cast<float *>(p.cvimg);
     const int nstage = (p.KTP + W_STT - 1) / W_STT;    // KTP is a multiple of 4; W_STT of 4 too: stages hold whole groups of 4 row tiles
-    constexpr int PW = (W_STT * NKC) / NW;             // pieces per wave and stage
+    constexpr int PW = (W_STT * NKC) / W_NWL;          // pieces per loader wave and stage
     const char *img = reinterpret_cast<const char *>(p.cb_img);
     const size_t img_bytes = (size_t)p.KTP * NKC * 1024;
-    auto issue = [&](int s) {
+    // piece i (< PW) of this wave's share of stage s
+    // Workgroup b walks the image's stages in the order rot, rot + 1, ..., wrapping round: the workgroups of the chip run the same
+    // level loop in step, and without the rotation every CU of an XCD asks its L2 for the same 24 KiB at the same moment.
+    const int rot = (int)((blockIdx.x * 13u) % (unsigned)nstage);
+    auto stage_of = [&](int s) { const int v = s + rot; return v >= nstage ? v - nstage : v; };
+    auto issue1 = [&](int s, int i) {
         const int slot = s % W_NST;
+        const int pc = (wave - NW) * PW + i;
+        size_t off = ((size_t)stage_of(s) * W_STT * NKC + pc) * 1024;
+        off = off < img_bytes ? off : img_bytes - 1024;      // pieces past the image repeat its last one: never read
+        dma_piece(uniform_ptr(img + off), lds0 + slot * STAGE + pc * 1024, (unsigned)lane * 16u);
+    };
+    auto issue = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int pc = wave * PW + i;
-            size_t off = ((size_t)s * W_STT * NKC + pc) * 1024;
-            off = off < img_bytes ? off : img_bytes - 1024;      // pieces past the image repeat its last one: never read
-            dma_piece(uniform_ptr(img + off), lds0 + slot * STAGE + pc * 1024, (unsigned)lane * 16u);
-        }
+        for (int i = 0; i < PW; ++i) issue1(s, i);
     };
     const int nlg = (p.levels + GL - 1) / GL;
     const int wq = (lane >> 2) & 3;
+    // The Gram blocks (172 floats each, 120 of them per token tile: 66 KB) are the same for every lane.  Read through a pointer
+    // hipcc can prove uniform they become scalar loads, which miss the 16 KB scalar cache and return one block per L2 round trip:
+    // 19 % of the kernel (tools/wide_timeline.py).  An opaque per-lane zero makes them vector loads of one address -- one cache
+    // line per instruction, dozens in flight.
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
     const long long tiles_per_round = (long long)gridDim.x * NW;
-    issue(0);
-    if (nstage > 1) issue(1);
+#ifdef W_TIMELINE
+    unsigned a_brow = 0, a_scan = 0, a_hand = 0, a_resc = 0, a_gram = 0, a_multi = 0, a_load = 0;
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+    if (wave >= NW) {
+        // ---- loader waves: the barriers of the computing waves, stage for stage and level for level, and the pieces between them.
+        // The ring runs D = W_NST - 1 stages ahead of the stage being multiplied (the slot of stage s - 1 is refilled with stage
+        // s + D once every wave has left it).
+        constexpr int D = W_NST - 1;
+        static_assert((D - 1) * PW <= 63, "vmcnt counts the stages in flight");
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i < nstage) issue(i);
+        for (long long tbase = (long long)blockIdx.x * NW; tbase < p.ntiles; tbase += tiles_per_round)
+            for (int l = 0; l < p.levels; ++l) {
+                for (int s = 0; s < nstage; ++s) {
+                    // this wave's pieces of stage s have landed; younger: its pieces of the stages after s already issued
+                    int ahead = nstage - 1 - s;
+                    ahead = ahead < D - 1 ? ahead : D - 1;
+                    switch (ahead) {
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW < 64 ? 2 * PW : 63) : "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW < 64 ? 3 * PW : 63) : "memory"); break;
+                    }
+                    __builtin_amdgcn_s_barrier();      // stage s is in LDS for everyone; everyone has left stage s - 1
+                    if (s + D < nstage) issue(s + D);  // into the slot stage s - 1 just left
+                }
+                __builtin_amdgcn_s_barrier();          // every wave has left the last stages: the ring is free
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                    if (i < nstage) issue(i);          // the next level's (or tile's) first stages land behind the serial part
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stages issued for a level that does not come
+        return;
+    }
     for (long long tbase = (long long)blockIdx.x * NW; tbase < p.ntiles; tbase += tiles_per_round) {
         const bool live = tbase + wave < p.ntiles;                        // a wave without tokens keeps the workgroup's schedule
         const long long tile = live ? tbase + wave : p.ntiles - 1;
         const long long t = tile * 64 + lane;                             // < tok_pad
         for (int lg = 0; lg < nlg; ++lg) {
+            W_T(t_l0);
             float Q[GL][CP];
             {
                 float buf[GP];
@@ -89,10 +152,13 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
             }
             float cvh[GL][CP];
             int codes[GL];
+            W_T(t_l1);
+            W_ACC(a_load, t_l0, t_l1);
             static_for<0, GL>([&](auto li_c) {
                 constexpr int li = decltype(li_c)::value;
                 const int l = lg * GL + li;
                 if (l < p.levels) {
+                    W_T(t_a);
                     float q[CP];
 #pragma unroll
                     for (int j = 0; j < CP; ++j) q[j] = Q[li][j];
@@ -138,49 +204,103 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
                     int bgrp[4];
 #pragma unroll
                     for (int T = 0; T < 4; ++T) { best[T] = -INFINITY; bgrp[T] = 0; }
-                    for (int s = 0; s < nstage; ++s) {
-                        // this wave's pieces of stage s have landed; younger: the pieces of stage s + 1 when it was issued
-                        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();      // everyone's pieces of stage s landed; everyone has left stage s - 1
-                        if (s + 2 < nstage) issue(s + 2);
-                        const char *sb = smem + (s % W_NST) * STAGE + lane * 16;
-                        int gcount = (p.KTP - s * W_STT) / 4;
-                        gcount = gcount < W_STT / 4 ? gcount : W_STT / 4;
-                        for (int gi = 0; gi < gcount; ++gi) {
-                            float mx[4];
+                    W_T(t_b);
+                    // The scores of a row tile are reduced one tile LATE: while tile t's 12 matrix instructions issue, the vector
+                    // pipe takes the maxima of tile t - 1 out of the other accumulator set (an MFMA leaves half of its 16 issue
+                    // cycles to other instructions; maxima placed behind a tile's own MFMAs wait out the last result's latency and
+                    // then hold the issue port -- with one computing wave per SIMD that is an idle matrix pipe).
+                    f32x4 scA[4], scB[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                u32x4 a[NKC];
+                    for (int T = 0; T < 4; ++T) scB[T] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    int pgrp = 0x7fffffff;             // row group of the pending tile (none yet: never taken)
+                    auto mm = [&](const u32x4 (&a)[NKC], f32x4 (&sc)[4]) {
+#ifdef W_NO_MFMA   /* tools build, timing only (wrong results): no matrix instructions -- what the refill alone takes */
+                        sc[0] = f32x4{f32_of(a[0][0]), f32_of(a[1][1]), f32_of(a[2][2]), 0.f};
+                        return;
+#endif
+                        // k-step outermost: four independent accumulators (one per token tile) between dependent instructions
 #pragma unroll
-                                for (int ks = 0; ks < NKC; ++ks) a[ks] = *reinterpret_cast<const u32x4 *>(sb + ((gi * 4 + i) * NKC + ks) * 1024);
-                                // k-step outermost: four independent accumulators (one per token tile) between dependent instructions
-                                f32x4 sc[4];
+                        for (int T = 0; T < 4; ++T) sc[T] = mfma16(a[0], B[T][0], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-                                for (int T = 0; T < 4; ++T) sc[T] = mfma16(a[0], B[T][0], f32x4{0.f, 0.f, 0.f, 0.f});
+                        for (int ks = 1; ks < NKC; ++ks)
 #pragma unroll
-                                for (int ks = 1; ks < NKC; ++ks)
+                            for (int T = 0; T < 4; ++T) sc[T] = mfma16(a[ks], B[T][ks], sc[T]);
+                    };
+                    // maxima of the pending tile (position pi = 0..3 inside its group of 4 row tiles); after the group's last tile the
+                    // running (maximum, group) per lane and token tile
+                    auto red = [&](const f32x4 (&sc)[4], int pi) {
 #pragma unroll
-                                    for (int T = 0; T < 4; ++T) sc[T] = mfma16(a[ks], B[T][ks], sc[T]);
-#pragma unroll
-                                for (int T = 0; T < 4; ++T) {
-                                    const float m012 = __builtin_elementwise_maximum(__builtin_elementwise_maximum(sc[T][0], sc[T][1]), sc[T][2]);
-                                    if (i == 0) mx[T] = __builtin_elementwise_maximum(m012, sc[T][3]);
-                                    else mx[T] = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m012, sc[T][3]), mx[T]);
-                                }
-                            }
-                            const int grp = s * (W_STT / 4) + gi;
+                        for (int T = 0; T < 4; ++T) {
+                            const float m012 = __builtin_elementwise_maximum(__builtin_elementwise_maximum(sc[T][0], sc[T][1]), sc[T][2]);
+                            if (pi == 0) mx[T] = __builtin_elementwise_maximum(m012, sc[T][3]);
+                            else mx[T] = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m012, sc[T][3]), mx[T]);
+                        }
+                        if (pi == 3) {
 #pragma unroll
                             for (int T = 0; T < 4; ++T) {
-                                const bool up = mx[T] > best[T];
+                                // equal maxima go to the lower row group whatever the order of the walk (duplicate rows, and the
+                                // pad rows that repeat row 0, must resolve to the lowest index)
+                                const bool up = mx[T] > best[T] || (mx[T] == best[T] && pgrp < bgrp[T]);
                                 best[T] = up ? mx[T] : best[T];
-                                bgrp[T] = up ? grp : bgrp[T];
+                                bgrp[T] = up ? pgrp : bgrp[T];
                             }
                         }
+                    };
+                    for (int s = 0; s < nstage; ++s) {
+#ifndef W_NO_BAR   /* tools build, timing only (races): no barrier per stage */
+                        __builtin_amdgcn_s_barrier();      // stage s is in LDS (the loaders waited for it); everyone has left stage s - 1
+#endif
+                        const char *sb = smem + (s % W_NST) * STAGE + lane * 16;
+                        const int sx = stage_of(s);            // the image stage in this ring slot
+                        int gcount = (p.KTP - sx * W_STT) / 4;
+                        gcount = gcount < W_STT / 4 ? gcount : W_STT / 4;
+                        // The fragments of a row tile (3 KiB: NKC ds_read_b128 per lane) are read one tile ahead into two alternating
+                        // register sets; the sched_group_barriers pin the order: next tile's reads, then the matrix instructions with
+                        // the pending tile's maxima between them
+                        u32x4 fa[NKC], fb[NKC];
+                        auto ldf = [&](u32x4 (&f)[NKC], int tl) {
+#pragma unroll
+                            for (int ks = 0; ks < NKC; ++ks) f[ks] = *reinterpret_cast<const u32x4 *>(sb + (tl * NKC + ks) * 1024);
+                        };
+                        auto order = [&]() {
+                            __builtin_amdgcn_sched_group_barrier(0x100, NKC, 0);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NKC - 8, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        const int ntl = gcount * 4;
+                        ldf(fa, 0);
+                        for (int gi = 0; gi < gcount; ++gi) {
+                            const int grp = sx * (W_STT / 4) + gi;
+                            // tile 0 of the group: pending = the last tile (3) of the group before (or nothing)
+                            ldf(fb, gi * 4 + 1);
+                            mm(fa, scA);
+                            red(scB, 3);
+                            order();
+                            pgrp = grp;
+                            ldf(fa, gi * 4 + 2);
+                            mm(fb, scB);
+                            red(scA, 0);
+                            order();
+                            ldf(fb, gi * 4 + 3);
+                            mm(fa, scA);
+                            red(scB, 1);
+                            order();
+                            ldf(fa, gi * 4 + 4 < ntl ? gi * 4 + 4 : ntl - 1);
+                            mm(fb, scB);
+                            red(scA, 2);
+                            order();
+                        }
                     }
-                    __builtin_amdgcn_s_barrier();          // every wave has left the last stages: the ring is free
-                    issue(0);                              // the next level's (or tile's) first stages land behind the serial part
-                    if (nstage > 1) issue(1);
+                    red(scB, 3);                           // the last tile of the level
+                    W_T(t_c);
+                    W_ACC(a_scan, t_b, t_c);
+                    __builtin_amdgcn_s_barrier();          // every wave has left the last stages: the ring is free (the loaders refill it)
                     // ---- the four lanes (g) of a token hand their (maximum, group) to the token's own lane
 #pragma unroll
                     for (int T = 0; T < 4; ++T) {
@@ -208,6 +328,8 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
                         }
                     }
                     if (!okq) { bgr = 0; bg = 0; amb = false; }
+                    W_T(t_d);
+                    W_ACC(a_hand, t_c, t_d);
                     // ---- the 16 rows behind that maximum, rescored in fp32 on the reference's q / ||q|| (k-ordered fma chain): first
                     // maximum wins
                     float xn[CP];
@@ -251,6 +373,8 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
                     }
                     if (!okq) brow = 0;
                     codes[li] = brow;
+                    W_T(t_e);
+                    W_ACC(a_resc, t_d, t_e);
                     // ---- straight-through value (rqae/model.py:218-220), as fp32 for the reconstruction
                     float cvp[CP];
 #pragma unroll
@@ -274,13 +398,26 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
                     for (int li2 = li + 1; li2 < GL; ++li2) {
                         const int l2 = lg * GL + li2;
                         if (l2 < p.levels) {
-                            const float *gb = p.gneg + ((size_t)l * p.L + l2) * GB;
+                            const f32x4 *gb4 = reinterpret_cast<const f32x4 *>(p.gneg + ((size_t)l * p.L + l2) * GB + vzero);
+                            // eight 16-byte pieces (32 values) at a time: the whole block at once would take 172 registers
 #pragma unroll
-                            for (int j = 0; j < CP; ++j)
+                            for (int w0 = 0; w0 < GB / 4; w0 += 8) {
+                                f32x4 gv[8];
 #pragma unroll
-                                for (int i = 0; i < CP; ++i) Q[li2][j] = __builtin_fmaf(gb[j * CP + i], cvp[i], Q[li2][j]);
+                                for (int w = 0; w < 8; ++w)
+                                    if (w0 + w < GB / 4) gv[w] = gb4[w0 + w];
+#pragma unroll
+                                for (int w = 0; w < 8; ++w)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const int f = 4 * (w0 + w) + e;
+                                        if (w0 + w < GB / 4 && f < CP * CP) Q[li2][f / CP] = __builtin_fmaf(gv[w][e], cvp[f % CP], Q[li2][f / CP]);
+                                    }
+                            }
                         }
                     }
+                    W_T(t_f);
+                    W_ACC(a_gram, t_e, t_f);
                 } else {
                     codes[li] = 0;
 #pragma unroll
@@ -293,6 +430,7 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
                     if (lg * GL + li < p.levels) p.idx[t * p.levels + lg * GL + li] = (long long)codes[li];
             }
             // ---- projections of the later level groups see this group's levels
+            W_T(t_m0);
             if (live)
                 for (int l2 = (lg + 1) * GL; l2 < p.levels; ++l2) {
                     const int o0 = (l2 / GL) * GP + (l2 % GL) * CP;
@@ -301,18 +439,39 @@ __global__ __launch_bounds__(NW * 64) void gram_levels_wide_kernel(LevParams p)
                     for (int j = 0; j < CP; ++j) v[j] = p.P[((size_t)((o0 + j) >> 4) * p.tok_pad + t) * 16 + ((o0 + j) & 15)];
 #pragma unroll
                     for (int li = 0; li < GL; ++li) {
-                        const float *gb = p.gneg + ((size_t)(lg * GL + li) * p.L + l2) * GB;
+                        const f32x4 *gb4 = reinterpret_cast<const f32x4 *>(p.gneg + ((size_t)(lg * GL + li) * p.L + l2) * GB + vzero);
+                        // half a block (22 pieces, 88 registers) per round trip: the chain is over (Q is dead), the registers are free, and
+                        // what this loop pays for is L2 round trips, not instructions
+                        constexpr int HB = (GB / 4 + 1) / 2;
 #pragma unroll
-                        for (int j = 0; j < CP; ++j)
+                        for (int w0 = 0; w0 < GB / 4; w0 += HB) {
+                            f32x4 gv[HB];
 #pragma unroll
-                            for (int i = 0; i < CP; ++i) v[j] = __builtin_fmaf(gb[j * CP + i], cvh[li][i], v[j]);
+                            for (int w = 0; w < HB; ++w)
+                                if (w0 + w < GB / 4) gv[w] = gb4[w0 + w];
+#pragma unroll
+                            for (int w = 0; w < HB; ++w)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int f = 4 * (w0 + w) + e;
+                                    if (w0 + w < GB / 4 && f < CP * CP) v[f / CP] = __builtin_fmaf(gv[w][e], cvh[li][f % CP], v[f / CP]);
+                                }
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < CP; ++j) p.P[((size_t)((o0 + j) >> 4) * p.tok_pad + t) * 16 + ((o0 + j) & 15)] = v[j];
                 }
+            W_T(t_m1);
+            W_ACC(a_multi, t_m0, t_m1);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stages issued for a level that does not come
+#ifdef W_TIMELINE
+    if (lane == 0) {
+        unsigned long long *o = g_wide_stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+        o[0] = __builtin_amdgcn_s_memtime() - t_entry;
+        o[1] = a_load; o[2] = a_brow; o[3] = a_scan; o[4] = a_hand; o[5] = a_resc; o[6] = a_gram; o[7] = a_multi;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ reconstruction, wide
@@ -332,7 +491,7 @@ struct RecWideParams {
 };
 
 template <int CP, int NLG>
-__host__ __device__ constexpr size_t wide_recon_lds_bytes() { return (size_t)W_NST * NLG * WideGeom<CP>::NKG * 1024 + 8 * 16 * 208; }
+__host__ __device__ constexpr size_t wide_recon_lds_bytes() { return (size_t)R_NST * NLG * WideGeom<CP>::NKG * 1024 + 8 * 16 * 208; }
 
 template <int CP, int NLG>
 __global__ __launch_bounds__(512) void gram_recon_wide_kernel(RecWideParams p)
@@ -344,16 +503,17 @@ __global__ __launch_bounds__(512) void gram_recon_wide_kernel(RecWideParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-    char *xb = smem + W_NST * STAGE + wave * (16 * XROW);
+    char *xb = smem + R_NST * STAGE + wave * (16 * XROW);
     constexpr int PW = (NKS + NW - 1) / NW;           // pieces per wave and stage (waves past the last piece repeat it)
-    auto issue = [&](int et_in, int slot) {
+    auto issue1 = [&](int et_in, int slot, int i) {
         const int et = et_in < p.NET ? et_in : p.NET - 1;
+        int q = wave + i * NW;
+        q = q < NKS ? q : NKS - 1;
+        dma_piece(uniform_ptr(p.wout_img + ((size_t)et * p.NKSC + q) * 512), lds0 + slot * STAGE + q * 1024, (unsigned)lane * 16u);
+    };
+    auto issue = [&](int et_in, int slot) {
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            int q = wave + i * NW;
-            q = q < NKS ? q : NKS - 1;
-            dma_piece(uniform_ptr(p.wout_img + ((size_t)et * p.NKSC + q) * 512), lds0 + slot * STAGE + q * 1024, (unsigned)lane * 16u);
-        }
+        for (int i = 0; i < PW; ++i) issue1(et_in, slot, i);
     };
     const long long ntile = (p.n_tokens + NW * 16 - 1) / (NW * 16);
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -418,25 +578,40 @@ __global__ __launch_bounds__(512) void gram_recon_wide_kernel(RecWideParams p)
             // this wave's pieces of stage e have landed; younger: the pieces of stage e + 1 (stores never wait here: they are older)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
             __builtin_amdgcn_s_barrier();
-            issue(e + 2, st == 0 ? 2 : st - 1);        // slot (e + 2) % 3 was read last in stage e - 1
+            const int nslot = st == 0 ? 2 : st - 1;    // slot (e + 2) % 3 was read last in stage e - 1: stage e + 2 goes there, one piece
+                                                       // behind each group of matrix instructions (a burst waits on the CU's address queue)
             const char *wb = smem + st * STAGE + lane * 16;
             f32x4 acc = *reinterpret_cast<const f32x4 *>(p.bias + 16 * e + 4 * g);
             f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-            // four fragments at a time: left alone hipcc hoists all NKS fragment reads above the first MFMA (160 more registers)
-#pragma unroll
-            for (int k0 = 0; k0 < NKS; k0 += 4) {
-                u32x4 fr[4];
+            // four fragments at a time, read one group ahead into two alternating register sets (sched_barrier pins the order: left
+            // alone hipcc either hoists all NKS reads above the first MFMA -- 160 more registers -- or reads, waits, multiplies)
+            u32x4 fr0[4], fr1[4];
+            auto ldg = [&](u32x4 (&f)[4], int k0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (k0 + i < NKS) fr[i] = *reinterpret_cast<const u32x4 *>(wb + (k0 + i) * 1024);
+                    if (k0 + i < NKS) f[i] = *reinterpret_cast<const u32x4 *>(wb + (k0 + i) * 1024);
+            };
+            auto mmg = [&](const u32x4 (&f)[4], int k0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (k0 + i < NKS) {
-                        if (i & 1) acc2 = mfma16(fr[i], cvB[k0 + i], acc2);
-                        else acc = mfma16(fr[i], cvB[k0 + i], acc);
+                        if (i & 1) acc2 = mfma16(f[i], cvB[k0 + i], acc2);
+                        else acc = mfma16(f[i], cvB[k0 + i], acc);
                     }
+            };
+            ldg(fr0, 0);
+#pragma unroll
+            for (int k0 = 0; k0 < NKS; k0 += 8) {
+                if (k0 + 4 < NKS) ldg(fr1, k0 + 4);
+                mmg(fr0, k0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k0 / 8 < PW) issue1(e + 2, nslot, k0 / 8);
+                if (k0 + 8 < NKS) ldg(fr0, k0 + 8);
+                if (k0 + 4 < NKS) mmg(fr1, k0 + 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int i = (NKS + 7) / 8; i < PW; ++i) issue1(e + 2, nslot, i);
             acc = f32x4{acc[0] + acc2[0], acc[1] + acc2[1], acc[2] + acc2[2], acc[3] + acc2[3]};
             if (tok_ok) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(p.out + (size_t)tok * p.d + 16 * e + 4 * g));
             st = st == 2 ? 0 : st + 1;

@@ -145,15 +145,15 @@ def test_gram_empty_batch_and_errors():
         m(torch.zeros(4, cfg["dim"], device=DEV))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 4, cfg["dim"]))
-    # shapes the arm does not serve: 'gram' says so, 'auto' takes the exact arm
-    c4 = synth.CONFIGS["C4"]
-    w4 = synth.weights(2, c4["dim"], c4["codebook_dim"], 2, c4["codebook_size"])
-    big = make_model(dict(c4, num_quantizers=2), w4, "gram")
+    # shapes the arm does not serve (codebook vectors wider than 13): 'gram' says so, 'auto' takes the exact arm
+    c14 = dict(dim=256, codebook_dim=14, codebook_size=2, num_quantizers=2)
+    w14 = synth.weights(2, c14["dim"], c14["codebook_dim"], 2, c14["codebook_size"])
+    big = make_model(c14, w14, "gram")
     with pytest.raises(RuntimeError, match="does not serve"):
-        big(torch.zeros(1, 4, c4["dim"], device=DEV))
-    auto = make_model(dict(c4, num_quantizers=2), w4, "auto")
-    exact = make_model(dict(c4, num_quantizers=2), w4, "exact")
-    x = torch.from_numpy(synth.activations(9, 64, c4["dim"])).to(DEV).view(1, 64, -1)
+        big(torch.zeros(1, 4, c14["dim"], device=DEV))
+    auto = make_model(c14, w14, "auto")
+    exact = make_model(c14, w14, "exact")
+    x = torch.from_numpy(synth.activations(9, 64, c14["dim"])).to(DEV).view(1, 64, -1)
     with torch.inference_mode():
         assert torch.equal(auto(x)[1], exact(x)[1])
 

@@ -23,7 +23,7 @@ __device__ unsigned long long g_wide_stamps[8192 * 8];
 #endif
 
 constexpr int W_STT = 8;        // row tiles per ring stage
-constexpr int W_NST = 5;        // ring slots: four stages in flight ahead of the one being multiplied
+constexpr int W_NST = 3;        // ring slots: the stage being multiplied, the one being written, one spare
 constexpr int R_NST = 3;        // ring slots of the reconstruction (40 KiB each at C4)
 constexpr int W_NWL = 2;        // loader waves per workgroup of the level chain (four measured the same)
 
@@ -55,7 +55,6 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
     static_assert((W_STT * NKC) % W_NWL == 0, "every loader wave issues the same number of pieces per stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const int c = p.c;
     char *xch = smem + W_NST * STAGE + wave * 4096;
     const float *cbf = p.cb_f32;                       // global (L2): K x c fp32, + 64 zero rows
@@ -65,21 +64,9 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
     const char *img = reinterpret_cast<const char *>(p.cb_img);
     const size_t img_bytes = (size_t)p.KTP * NKC * 1024;
     // piece i (< PW) of this wave's share of stage s
-    // Workgroup b walks the image's stages in the order rot, rot + 1, ..., wrapping round: the workgroups of the chip run the same
-    // level loop in step, and without the rotation every CU of an XCD asks its L2 for the same 24 KiB at the same moment.
-    const int rot = (int)((blockIdx.x * 13u) % (unsigned)nstage);
-    auto stage_of = [&](int s) { const int v = s + rot; return v >= nstage ? v - nstage : v; };
-    auto issue1 = [&](int s, int i) {
-        const int slot = s % W_NST;
-        const int pc = (wave - NW) * PW + i;
-        size_t off = ((size_t)stage_of(s) * W_STT * NKC + pc) * 1024;
-        off = off < img_bytes ? off : img_bytes - 1024;      // pieces past the image repeat its last one: never read
-        dma_piece(uniform_ptr(img + off), lds0 + slot * STAGE + pc * 1024, (unsigned)lane * 16u);
-    };
-    auto issue = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) issue1(s, i);
-    };
+    // (Walking the stages in a different order per workgroup -- so that the CUs of an XCD do not all ask their L2 for the same 24 KiB at
+    //  the same moment -- was measured and changes nothing; the walk is in row order, which also keeps the tie rule a plain `>`.)
+    auto stage_of = [&](int s) { return s; };
     const int nlg = (p.levels + GL - 1) / GL;
     const int wq = (lane >> 2) & 3;
     // The Gram blocks (172 floats each, 120 of them per token tile: 66 KB) are the same for every lane.  Read through a pointer
@@ -94,35 +81,71 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
     if (wave >= NW) {
-        // ---- loader waves: the barriers of the computing waves, stage for stage and level for level, and the pieces between them.
-        // The ring runs D = W_NST - 1 stages ahead of the stage being multiplied (the slot of stage s - 1 is refilled with stage
-        // s + D once every wave has left it).
-        constexpr int D = W_NST - 1;
-        static_assert((D - 1) * PW <= 63, "vmcnt counts the stages in flight");
+        // ---- loader waves: the barriers of the computing waves, stage for stage and level for level, and the image between them.
+        // REGISTER-STAGED: plain global loads into registers, ds_write into the ring one stage ahead of the stage being multiplied
+        // (tools build -DW_LOADER_DMA keeps the LDS-DMA form for comparison).  Stage k is loaded after barrier(k - 3), written into
+        // slot k % W_NST before barrier(k - 1) and read by the computing waves after barrier(k).
+        const int lw = wave - NW;
+        constexpr int NR = 3;                          // register sets: loads of up to two stages in flight behind the one being written
+        u32x4 R[NR][PW];
+        auto gload = [&](int s, u32x4 (&r)[PW]) {
+#ifdef W_NO_LOAD   /* tools build, timing only (wrong results): the loaders keep the barriers and move nothing */
+            return;
+#endif
 #pragma unroll
-        for (int i = 0; i < D; ++i)
-            if (i < nstage) issue(i);
+            for (int i = 0; i < PW; ++i) {
+                const int pc = lw * PW + i;
+                size_t off = ((size_t)stage_of(s) * W_STT * NKC + pc) * 1024;
+                off = off < img_bytes ? off : img_bytes - 1024;
+                r[i] = *reinterpret_cast<const u32x4 *>(img + off + lane * 16);
+            }
+        };
+        auto lwrite = [&](int s, const u32x4 (&r)[PW]) {
+#ifdef W_NO_LOAD
+            return;
+#endif
+            char *dst = smem + (s % W_NST) * STAGE + lw * PW * 1024 + lane * 16;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) *reinterpret_cast<u32x4 *>(dst + i * 1024) = r[i];
+        };
+        // per level: stages 0 and 1 are written before the level's first barrier; loads run two stages ahead of the writes
+        auto prologue = [&]() {
+            gload(0, R[0]);
+            if (nstage > 1) gload(1, R[1]);
+            if (nstage > 2) gload(2, R[2]);
+            if (nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+            else if (nstage > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lwrite(0, R[0]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        prologue();
         for (long long tbase = (long long)blockIdx.x * NW; tbase < p.ntiles; tbase += tiles_per_round)
             for (int l = 0; l < p.levels; ++l) {
-                for (int s = 0; s < nstage; ++s) {
-                    // this wave's pieces of stage s have landed; younger: its pieces of the stages after s already issued
-                    int ahead = nstage - 1 - s;
-                    ahead = ahead < D - 1 ? ahead : D - 1;
-                    switch (ahead) {
-                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory"); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW < 64 ? 2 * PW : 63) : "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW < 64 ? 3 * PW : 63) : "memory"); break;
+                // invariant at the top of stage s: stage s is written; loads of stages s + 1 and s + 2 are in flight (sets
+                // (s + 1) % 3 and (s + 2) % 3)
+                for (int s = 0; s < nstage; s += 3) {
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int ss = s + u;
+                        if (ss < nstage) {
+                            __builtin_amdgcn_s_barrier();      // stage ss is in LDS for everyone; everyone has left stage ss - 1
+                            if (ss + 3 < nstage) gload(ss + 3, R[u]);                     // set ss % 3 == u: stage ss was written from it
+                            if (ss + 1 < nstage) {
+                                // stage ss + 1's loads (set (u + 1) % 3) have landed; younger: those of ss + 2 and ss + 3
+                                const int younger = (ss + 3 < nstage ? 2 : ss + 2 < nstage ? 1 : 0);
+                                if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+                                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                lwrite(ss + 1, R[(u + 1) % 3]);
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            }
+                        }
                     }
-                    __builtin_amdgcn_s_barrier();      // stage s is in LDS for everyone; everyone has left stage s - 1
-                    if (s + D < nstage) issue(s + D);  // into the slot stage s - 1 just left
                 }
                 __builtin_amdgcn_s_barrier();          // every wave has left the last stages: the ring is free
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-                    if (i < nstage) issue(i);          // the next level's (or tile's) first stages land behind the serial part
+                prologue();                            // the next level's (or tile's) first stages, behind the serial part
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stages issued for a level that does not come
         return;
     }
     for (long long tbase = (long long)blockIdx.x * NW; tbase < p.ntiles; tbase += tiles_per_round) {
@@ -239,9 +262,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
                         if (pi == 3) {
 #pragma unroll
                             for (int T = 0; T < 4; ++T) {
-                                // equal maxima go to the lower row group whatever the order of the walk (duplicate rows, and the
-                                // pad rows that repeat row 0, must resolve to the lowest index)
-                                const bool up = mx[T] > best[T] || (mx[T] == best[T] && pgrp < bgrp[T]);
+                                const bool up = mx[T] > best[T];          // groups arrive in row order: the first maximum keeps ties
                                 best[T] = up ? mx[T] : best[T];
                                 bgrp[T] = up ? pgrp : bgrp[T];
                             }
@@ -260,6 +281,9 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
                         // the pending tile's maxima between them
                         u32x4 fa[NKC], fb[NKC];
                         auto ldf = [&](u32x4 (&f)[NKC], int tl) {
+#ifdef W_NO_LDS   /* tools build, timing only (wrong results): the stage's first two row tiles' fragments for every tile */
+                            if (tl > 1) return;
+#endif
 #pragma unroll
                             for (int ks = 0; ks < NKC; ++ks) f[ks] = *reinterpret_cast<const u32x4 *>(sb + (tl * NKC + ks) * 1024);
                         };

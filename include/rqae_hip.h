@@ -217,7 +217,8 @@ size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_token
  *   proj        3: LDS-DMA projection kernel, 2: register-pipelined, 1: first form                               (3)
  *   recon       2: token-stationary reconstruction with 512-byte store rows, 1: weights-stationary               (2)
  *   lean_levels level chain of a single level group (levels <= 8): 2 = fp32 straight-through values handed to the
- *               reconstruction kernel, 16 waves per workgroup; 1 = the same with 8 waves; 0 = the first form     (2)
+ *               reconstruction kernel, 16 waves per workgroup, tables resident in LDS; 1 = the same with 8 waves;
+ *               0 = the first form; 3 = the streamed form (codebook image through a 24 KB ring by loader waves)     (2)
  *   pipe_chunk  > 0: passes of that many tokens, reconstruction of pass i on a second stream beside pass i+1    (0) */
 typedef struct rqae_hip_gram_options {
     int32_t size;
@@ -237,6 +238,17 @@ int rqae_hip_encode_gram_gemma_supported(int d, int c, int K, int L, int codeboo
 int rqae_hip_encode_gram_gemma(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *hs, int hs_dtype,
                                float eps, int64_t n_tokens, int levels, float *q_out, int64_t *indices, float *inv_rms,
                                void *workspace, const rqae_hip_gram_options *options, void *stream);
+/* RQAE.hook's arithmetic end to end for a Gemma-2 layer output, IN PLACE (rqae/model.py:276-289 with the default no-op store and
+ * replace = True): the norm folded into the projection as above, the level chain, and a reconstruction kernel whose stores are the
+ * way back -- new = (quantized / (1 + w)) / rs (rqae/llm.py:68-73) rounded to hs' own dtype over hs, rows of the first position of
+ * every sequence (token % S == 0) left as they are when skip_bos != 0 (rqae/model.py:285-286).  The fp32 `quantized` tensor is never
+ * written: 2 d + 2 d bytes per token move instead of 2 d + 4 d + (4 d + 2 d + 2 d).  inv_1pw [d] fp32 = 1 / (1 + norm.weight),
+ * allocated in whole KiB; inv_rms [n_tokens] fp32 is scratch (it holds rs afterwards); levels <= 8.  Tier-2 parity for the codes;
+ * the patched values within one rounding step of hs' dtype of the unfused path's. */
+int rqae_hip_encode_gram_gemma_patch(const void *packed, int d, int c, int K, int L, int codebook_shared, void *hs_inout, int hs_dtype,
+                                     float eps, const float *inv_1pw, int S, int skip_bos, int64_t n_tokens, int levels,
+                                     int64_t *indices, float *inv_rms, void *workspace, const rqae_hip_gram_options *options,
+                                     void *stream);
 /* RQAE.decode (rqae/model.py:250-252) on the matrix-core arm, every level of indices [n_tokens][levels] selected: the decode sum
  * as rqae_hip_encode_gram's reconstruction kernel computes it (bf16-piece products, fp32 accumulation: within 1e-6 relative of
  * rqae_hip_decode, not its bits), codebook rows gathered by the codes in the kernel.  HBM-write-bound: 9 216 + 8 levels bytes per

@@ -47,6 +47,7 @@ SYMBOLS = (
     "rqae_hip_encode_gram",
     "rqae_hip_encode_gram_gemma_supported",
     "rqae_hip_encode_gram_gemma",
+    "rqae_hip_encode_gram_gemma_patch",
     "rqae_hip_encode_gram_phases",
     "rqae_hip_decode_gram_supported",
     "rqae_hip_decode_gram",
@@ -138,6 +139,9 @@ def lib():
     L.rqae_hip_encode_gram_gemma_supported.restype = i
     L.rqae_hip_encode_gram_gemma.argtypes = [vp, i, i, i, i, i, vp, i, ctypes.c_float, i64, i, vp, vp, vp, vp, ctypes.POINTER(GramOptions), vp]
     L.rqae_hip_encode_gram_gemma.restype = i
+    L.rqae_hip_encode_gram_gemma_patch.argtypes = [vp, i, i, i, i, i, vp, i, ctypes.c_float, vp, i, i, i64, i, vp, vp, vp,
+                                                   ctypes.POINTER(GramOptions), vp]
+    L.rqae_hip_encode_gram_gemma_patch.restype = i
     L.rqae_hip_encode_gram_phases.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, ctypes.POINTER(GramOptions), vp,
                                               ctypes.POINTER(ctypes.c_float)]
     L.rqae_hip_encode_gram_phases.restype = i
@@ -326,6 +330,41 @@ def encode_gram_gemma(gpacked_scaled, dims, hs: torch.Tensor, eps: float, levels
                                                   _stream(hs.device))
         _check(rc, "rqae_hip_encode_gram_gemma")
     return q, idx, rs
+
+
+def encode_gram_gemma_patch(gpacked_scaled, dims, hs: torch.Tensor, inv_1pw: torch.Tensor, eps: float, levels: int, skip_bos: bool,
+                            workspace: torch.Tensor | None = None, options: GramOptions | None = None):
+    """RQAE.hook for a Gemma-2 layer output end to end, in place (include/rqae_hip.h: rqae_hip_encode_gram_gemma_patch): hs [B,S,d]
+    {bf16,f16} is overwritten with denorm(forward(norm(hs))) (BOS rows kept when skip_bos); returns (indices [B,S,levels] i64,
+    inv_rms [B,S] f32).  ``inv_1pw``: 1 / (1 + norm.weight), fp32, padded to a whole KiB (``gemma_inv_1pw``)."""
+    _require_cuda(hs, "hidden states")
+    if hs.dtype not in (torch.bfloat16, torch.float16) or not hs.is_contiguous() or hs.dim() != 3:
+        raise RuntimeError("encode_gram_gemma_patch: hidden states must be contiguous [B,S,d] bf16/f16")
+    d, c, K, L_ = dims
+    B, S, _ = hs.shape
+    n = B * S
+    idx = torch.empty((B, S, levels), dtype=torch.int64, device=hs.device)
+    rs = torch.empty((B, S), dtype=torch.float32, device=hs.device)
+    if n:
+        need = gram_workspace_bytes(dims, n, levels)
+        if workspace is None or workspace.numel() * workspace.element_size() < need or workspace.device != hs.device:
+            workspace = torch.empty(need, dtype=torch.uint8, device=hs.device)
+        with torch.cuda.device(hs.device):
+            rc = lib().rqae_hip_encode_gram_gemma_patch(gpacked_scaled.data_ptr(), d, c, K, L_, 1, hs.data_ptr(), _X_DTYPES[hs.dtype],
+                                                        float(eps), inv_1pw.data_ptr(), S, int(bool(skip_bos)), n, levels,
+                                                        idx.data_ptr(), rs.data_ptr(), workspace.data_ptr(),
+                                                        ctypes.byref(options) if options is not None else None, _stream(hs.device))
+        _check(rc, "rqae_hip_encode_gram_gemma_patch")
+    return idx, rs
+
+
+def gemma_inv_1pw(norm_weight: torch.Tensor) -> torch.Tensor:
+    """1 / (1 + w) as fp32 on w's device, zero-padded to a whole KiB (the reconstruction kernel stages it by 1-KiB pieces)."""
+    w = norm_weight.detach().float()
+    d = w.numel()
+    out = torch.zeros(((d * 4 + 1023) // 1024) * 256, dtype=torch.float32, device=w.device)
+    out[:d] = 1.0 / (1.0 + w)
+    return out
 
 
 def decode_gram_supported(dims, codebook_shared: bool, levels: int) -> bool:

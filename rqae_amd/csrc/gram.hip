@@ -1292,7 +1292,7 @@ int make_tuning(const rqae_hip_gram_options *o, Tuning &t)
     if (o->size != (int32_t)sizeof(rqae_hip_gram_options)) return gfail("gram options: size %d, this library expects %d", (int)o->size, (int)sizeof(rqae_hip_gram_options));
     if (o->fused >= 0) t.fused = o->fused != 0;
     if (o->pipe_chunk >= 0) t.pipe_chunk = o->pipe_chunk == 0 ? 0 : ((o->pipe_chunk + 255) & ~255LL);
-    if (o->proj > 3 || o->recon > 2 || o->lean_levels > 2) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
+    if (o->proj > 3 || o->recon > 2 || o->lean_levels > 3) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
     if (o->proj >= 1) t.proj = o->proj;
     if (o->recon >= 1) t.recon = o->recon;
     if (o->lean_levels >= 0) t.lev2 = o->lean_levels;
@@ -1478,7 +1478,8 @@ namespace {
 // chunk (rqae_hip_encode_gram_phases)
 int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codebook_shared, const void *x, int x_dtype,
                      int64_t n_tokens, int levels, float *q_out, int64_t *indices, void *workspace, const rqae_hip_gram_options *opts,
-                     void *stream, hipEvent_t *ev, float *inv_rms = nullptr, float eps = 0.0f)
+                     void *stream, hipEvent_t *ev, float *inv_rms = nullptr, float eps = 0.0f, const float *inv1pw = nullptr, int patch_S = 0,
+                     int patch_skip_bos = 0)
 {
     Tuning tun;
     if (int rc = make_tuning(opts, tun)) return rc;
@@ -1553,6 +1554,10 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW <= 160 * 1024;
     // one level group: the lean level chain hands fp32 straight-through values to the reconstruction (which splits them)
     const bool lev2 = tuning().lev2 && g.CP <= 5 && levels <= 8 && g.shared_cb && g.NKC == 1 && lev2_lds_bytes(c, K) <= 160 * 1024 && (!q_out || recon2_ok);
+    // inv1pw != NULL: the hook's way back folded into the reconstruction's stores (gram_fused_kernel MODE 6): x is patched in place
+    const bool patch = inv1pw != nullptr;
+    if (patch && !(inv_rms && recon2_ok && lev2 && patch_S >= 1))
+        return gfail("encode_gram_gemma_patch: needs the folded norm, one level group (levels <= 8) and the token-stationary reconstruction");
     auto phaseAB = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark, bool strict) -> int {
         if (mark) G_TRY(hipEventRecord(ev[0], s));
         // ---- A
@@ -1670,7 +1675,27 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                 G_TRY(hipGetLastError());
                 return 0;
             };
-            return nw == 8 ? go(gram_levels_wide_kernel<13, 8>) : go(gram_levels_wide_kernel<13, 4>);
+            return nw == 8 ? go(gram_levels_wide_kernel<13, 8, true>) : go(gram_levels_wide_kernel<13, 4, true>);
+        }
+        if (lev2 && tuning().lev2 == 3 && c == g.CP) {
+            // the streamed form of gram_wide.hpp for one level group: 8 computing waves (two per SIMD) + 2 loader waves, the codebook
+            // image through a 24 KB ring instead of resident, fp32 rows and Gram blocks from L2: 56 KB of LDS instead of 156
+            LevParams pb;
+            pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
+            pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
+            pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
+            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
+            const int nw = 8;
+            const size_t lds = wide_levels_lds_bytes(g.NKC, nw);
+            long long nb = (pb.ntiles + nw - 1) / nw;
+            if (nb > ncu) nb = ncu;
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3((nw + W_NWL) * 64), lds, s, pb);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            return g.CP == 4 ? go(gram_levels_wide_kernel<4, 8, false>) : go(gram_levels_wide_kernel<5, 8, false>);
         }
         if (lev2) {
             Lev2Params pl;
@@ -1743,7 +1768,27 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     auto phaseC = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark) -> int {
         if (mark) G_TRY(hipEventRecord(ev[2], s));
         // ---- C
-        if (q_out && wide) {
+        if (patch) {
+            FusedParams pf;
+            memset(&pf, 0, sizeof(pf));
+            pf.wout_img = v.wout_img; pf.bias = v.bias_prefix + (size_t)(levels - 1) * d; pf.out = nullptr;
+            pf.cvimg = cvimg; pf.cvf = reinterpret_cast<const float *>(cvimg); pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c; pf.levels = levels; pf.L = L;
+            pf.KSA = g.KSA; pf.NOG = g.NOG; pf.NET = g.NET; pf.NKSC = g.NKSC; pf.stagger = 0; pf.dump = dump; pf.nks_live = nks;
+            pf.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768);
+            pf.hs_out = const_cast<char *>(static_cast<const char *>(x)) + (size_t)t0 * d * xs; pf.hs_dtype = x_dtype; pf.inv1pw = inv1pw;
+            pf.inv_rms = inv_rms + t0; pf.tok0 = t0; pf.S = patch_S; pf.skip_bos = patch_skip_bos;
+            long long nb = (nt + F_TILE - 1) / F_TILE;
+            if (nb > ncu) nb = ncu;
+            const size_t lds = 2 * pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW;
+            if (lds > 160 * 1024) return gfail("encode_gram_gemma_patch: d=%d does not leave room for 1 / (1 + w) in LDS", d);
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(F_NW * 64), lds, s, pf);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            if (int rc = g.CP == 4 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 6>) : go(gram_fused_kernel<RQAE_X_BF16, 5, true, 6>)) return rc;
+        } else if (q_out && wide) {
             RecWideParams pw;
             pw.wout_img = v.wout_img; pw.bias = v.bias_prefix + (size_t)(levels - 1) * d; pw.cvf = reinterpret_cast<const float *>(cvimg);
             pw.out = q_out + (size_t)t0 * d; pw.n_tokens = nt; pw.tok_pad = tp; pw.d = d; pw.NKSC = g.NKSC; pw.NET = g.NET; pw.levels = levels;
@@ -1828,7 +1873,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     // ---- pipelined schedule: passes of pipe_chunk tokens; the reconstruction of pass i (HBM writes) runs on the second stream
     // beside the projection (HBM reads) and the level chain (matrix cores, no memory traffic) of pass i+1.  Every workgroup of
     // these kernels fills a CU's LDS, so capped grids split the CUs between the two streams.
-    if (!ev && q_out && tuning().pipe_chunk > 0 && n_tokens > tuning().pipe_chunk && tuning().pipe_chunk <= tp) {
+    if (!ev && q_out && !patch && tuning().pipe_chunk > 0 && n_tokens > tuning().pipe_chunk && tuning().pipe_chunk <= tp) {
         Side *sd = side_for_device();
         if (sd) {
             const long long pch = tuning().pipe_chunk;
@@ -1890,6 +1935,23 @@ int rqae_hip_encode_gram_gemma(const void *packed, int d, int c, int K, int L, i
         return gfail("encode_gram_gemma: unsupported shape / dtype d=%d c=%d K=%d L=%d hs_dtype=%d", d, c, K, L, hs_dtype);
     return encode_gram_impl(packed, d, c, K, L, codebook_shared, hs, hs_dtype, n_tokens, levels, q_out, indices, workspace, options,
                             stream, nullptr, inv_rms, eps);
+}
+
+// The whole of RQAE.hook's arithmetic for a Gemma-2 layer output, in place (rqae/model.py:276-289 with store = None, replace = True):
+// norm folded into the projection, level chain, and the reconstruction kernel writes new = (q / (1 + w)) / rs over hs in its own
+// dtype, BOS rows (token % S == 0) kept when skip_bos.  `quantized` (fp32) is never written.  inv_1pw = 1 / (1 + norm.weight), [d]
+// padded to a whole KiB; inv_rms: [n_tokens] floats of scratch.
+int rqae_hip_encode_gram_gemma_patch(const void *packed, int d, int c, int K, int L, int codebook_shared, void *hs_inout, int hs_dtype,
+                                     float eps, const float *inv_1pw, int S, int skip_bos, int64_t n_tokens, int levels,
+                                     int64_t *indices, float *inv_rms, void *workspace, const rqae_hip_gram_options *options,
+                                     void *stream)
+{
+    if (!inv_rms || !inv_1pw || !hs_inout) return gfail("encode_gram_gemma_patch: null pointer");
+    if (S < 1) return gfail("encode_gram_gemma_patch: S=%d", S);
+    if (!rqae_hip_encode_gram_gemma_supported(d, c, K, L, codebook_shared, hs_dtype) || levels > 8)
+        return gfail("encode_gram_gemma_patch: unsupported shape / dtype d=%d c=%d K=%d L=%d levels=%d hs_dtype=%d", d, c, K, L, levels, hs_dtype);
+    return encode_gram_impl(packed, d, c, K, L, codebook_shared, hs_inout, hs_dtype, n_tokens, levels, nullptr, indices, workspace, options,
+                            stream, nullptr, inv_rms, eps, inv_1pw, S, skip_bos);
 }
 
 // RQAE.decode on the matrix-core arm: out = sum_l (W_out[l] codebook[idx_l] + b_out[l]) as the reconstruction kernel computes it

@@ -49,8 +49,13 @@ struct FusedParams {
     const float *cvf;          // MODE 3: fp32 straight-through values, level planes [8][tok_pad][CP]
     const void *codes;         // MODE 4: code indices [n_tokens][levels] (int64 / int32 / uint16 by the XT parameter: RQAE_IDX_*)
     int *status;               // MODE 4: include/rqae_hip.h "Status word" (a code outside -K..K-1), or NULL
-    float *inv_rms;            // MODE 5: 1 / sqrt(mean(x^2) + eps) per token, written for the way back (rqae_hip_gemma_denorm_patch)
+    float *inv_rms;            // MODE 5: 1 / sqrt(mean(x^2) + eps) per token, written for the way back; MODE 6 reads it
     float eps;                 // MODE 5
+    // MODE 6 (MODE 3 with Gemma's denorm, BOS skip and the write-back into the layer output in the store path):
+    void *hs_out;              // [n_tokens][d] fp16 / bf16 (hs_dtype: RQAE_X_F16 / RQAE_X_BF16), the hooked layer's output, patched in place
+    const float *inv1pw;       // [d] (+ slack to a whole KiB): 1 / (1 + norm.weight)
+    long long tok0;            // global index of this launch's first token (BOS rows: (tok0 + t) % S == 0)
+    int S, skip_bos, hs_dtype;
 };
 
 constexpr int F_NW = 8;                 // waves per workgroup
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
     // C
     const float *sbias = reinterpret_cast<const float *>(smem);
     const unsigned bias_bytes = (unsigned)pad1k((size_t)p.d * 4);
-    const unsigned off_wo = bias_bytes;
+    const unsigned off_wo = MODE == 6 ? 2 * bias_bytes : bias_bytes;      // MODE 6 keeps 1 / (1 + w) behind the bias sums
     char *trb = smem + off_wo + 3 * STAGE_C + wave * F_TRW;
 
     const int nchunks = p.KSA / KC;
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if constexpr (MODE == 3) {
+        if constexpr (MODE == 3 || MODE == 6) {
             // fp32 straight-through values written by gram_levels2_kernel, level planes [GL][tok_pad][CP] (zeros past the depth in use): the
             // split into bf16 pieces happens here, on the memory-bound side
             float cvf[GL][CP];
@@ -750,6 +755,18 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
             };
             for (int q = wave; q < (int)(bias_bytes >> 10); q += F_NW)
                 dma_piece(uniform_ptr(reinterpret_cast<const char *>(p.bias) + (size_t)q * 1024), lds0 + q * 1024, lane16);
+            // MODE 6: per token 1 / rs (lane l holds token l & 31 of the wave) and whether it is a BOS row; 1 / (1 + w) into LDS
+            float irs_tok = 1.0f;
+            unsigned long long bosmask = 0ull;
+            if constexpr (MODE == 6) {
+                for (int q = wave; q < (int)(bias_bytes >> 10); q += F_NW)
+                    dma_piece(uniform_ptr(reinterpret_cast<const char *>(p.inv1pw) + (size_t)q * 1024), lds0 + bias_bytes + q * 1024, lane16);
+                long long tk = tw0 + tl;
+                tk = tk < tile_end ? tk : tile_end - 1;
+                irs_tok = 1.0f / p.inv_rms[tk];
+                bosmask = __builtin_amdgcn_ballot_w64(p.skip_bos && ((p.tok0 + tk) % p.S) == 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below start from the pieces issued next
+            }
             issueC(0, 0);
             if (nstg > 1) issueC(1, 1);
             constexpr int PCS = (F_ETS * NKS) / F_NW;     // W_out pieces per wave and stage
@@ -832,6 +849,32 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                                     const int rr = 2 * i + (lane >> 5);
                                     const f32x4 v = *reinterpret_cast<const f32x4 *>(trb + rr * F_TRS + (lane & 31) * 16);
                                     const int row = 16 * T + 8 * hh + rr;
+                                    if constexpr (MODE == 6) {
+                                        // RQAE.hook's way back (rqae/model.py:284-289, rqae/llm.py:68-73): new = (q / (1 + w)) / rs, BOS rows keep
+                                        // the layer's own values, the result goes over the layer output in its dtype.  Two multiplications by
+                                        // reciprocals instead of the reference's two divisions (this arm is Tier 2; the difference is below the
+                                        // fp16 / bf16 rounding that follows).  A BOS row's store goes to the dump rows: the store count stays static.
+                                        if (fullw || (tw0 + row < tile_end && el0 < p.d)) {
+                                            const float r = __shfl(irs_tok, row);
+                                            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(smem + bias_bytes + (size_t)el0 * 4);
+                                            const float o0 = v[0] * w4[0] * r, o1 = v[1] * w4[1] * r, o2 = v[2] * w4[2] * r, o3 = v[3] * w4[3] * r;
+                                            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                                            u32x2 pk;
+                                            if (p.hs_dtype == RQAE_X_F16) {
+                                                typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+                                                pk[0] = __builtin_bit_cast(unsigned, h2{(_Float16)o0, (_Float16)o1});
+                                                pk[1] = __builtin_bit_cast(unsigned, h2{(_Float16)o2, (_Float16)o3});
+                                            } else {
+                                                typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+                                                pk[0] = __builtin_bit_cast(unsigned, b2{(__bf16)o0, (__bf16)o1});
+                                                pk[1] = __builtin_bit_cast(unsigned, b2{(__bf16)o2, (__bf16)o3});
+                                            }
+                                            const bool bos = (bosmask >> row) & 1ull;
+                                            char *dst = bos ? reinterpret_cast<char *>(p.dump) + lane * 8
+                                                            : static_cast<char *>(p.hs_out) + ((size_t)(tw0 + row) * p.d + el0) * 2;
+                                            *reinterpret_cast<u32x2 *>(dst) = pk;
+                                        }
+                                    } else
 #ifdef FQ_NOSTORE   /* tools build: the reconstruction is computed and transposed but not stored */
                                     if (p.n_tokens < 0)
 #else

@@ -28,14 +28,15 @@ constexpr int R_NST = 3;        // ring slots of the reconstruction (40 KiB each
 constexpr int W_NWL = 2;        // loader waves per workgroup of the level chain (four measured the same)
 
 template <int CP> struct WideGeom {
-    static constexpr int GL = 4;                                   // levels per level group (gl_of)
+    static constexpr int GL = CP <= 8 ? 8 : 4;                     // levels per level group (gl_of)
     static constexpr int GP = ((GL * CP + 15) / 16) * 16;          // projection outputs per group, whole 16-wide tiles
     static constexpr int NKC = (6 * CP + 31) / 32;                 // k-steps of the cosine contraction
     static constexpr int GS = ((6 * CP * GL + 31) / 32) * 32;      // reconstruction slots per group
     static constexpr int NKG = GS / 32;                            // reconstruction k-steps per group
     static constexpr int GB = (CP * CP + 3) & ~3;
     static constexpr int STAGE = W_STT * NKC * 1024;               // bytes per ring stage
-    static constexpr int CVS = 16;                                 // floats per token and level in the value planes (c <= 13, padded)
+    static constexpr int CVS = CP <= 5 ? CP : 16;                  // floats per token and level in the value planes: CP (what the
+                                                                   // one-group reconstruction, gram_fused_kernel MODE 3, reads) or 16
 };
 
 __host__ __device__ inline size_t wide_levels_lds_bytes(int nkc, int nw) { return (size_t)W_NST * W_STT * nkc * 1024 + (size_t)nw * 4096; }   // nw = computing waves
@@ -46,12 +47,14 @@ __host__ __device__ inline size_t wide_levels_lds_bytes(int nkc, int nw) { retur
 // Waves 0 .. NW-1 compute; waves NW, NW+1 only move the image: a global_load_lds occupies its wave's issue for 100-185 cycles
 // (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), and with one computing wave per SIMD a wave that waits there is an idle matrix
 // pipe -- measured: 41.5 cycles per matrix instruction with the pieces issued by the computing waves, 16.3 with no refill at all.
-template <int CP, int NW>
-__global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(LevParams p)
+// MULTI: more than one level group (later groups' projections are corrected through the workspace).  NW = 4: one computing wave
+// per SIMD (C4 at its stated batch); NW = 8: two, so that one wave's serial part (rescoring, Gram updates) runs behind the other's scan.
+template <int CP, int NW, bool MULTI = true>
+__global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_levels_wide_kernel(LevParams p)
 {
     using G = WideGeom<CP>;
     constexpr int GL = G::GL, GP = G::GP, NKC = G::NKC, GB = G::GB, STAGE = G::STAGE, CVS = G::CVS;
-    static_assert(NKC == 3, "three k-steps per cosine contraction");
+    static_assert(NKC == 1 || NKC == 3, "one or three k-steps per cosine contraction");
     static_assert((W_STT * NKC) % W_NWL == 0, "every loader wave issues the same number of pieces per stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
@@ -173,8 +176,17 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
 #pragma unroll
                     for (int j = 0; j < CP; ++j) Q[li][j] = buf[li * CP + j];
             }
-            float cvh[GL][CP];
+            float cvh[MULTI ? GL : 1][CP];
             int codes[GL];
+            if constexpr (!MULTI) {
+                // planes of the levels not run (max_layers < GL) are zeros for the reconstruction
+                if (live)
+                    for (int lz = p.levels; lz < GL; ++lz) {
+                        float *dst = cvf + ((size_t)lz * p.tok_pad + t) * CVS;
+#pragma unroll
+                        for (int j = 0; j < CVS; ++j) dst[j] = 0.0f;
+                    }
+            }
             W_T(t_l1);
             W_ACC(a_load, t_l0, t_l1);
             static_for<0, GL>([&](auto li_c) {
@@ -289,12 +301,20 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
                         };
                         auto order = [&]() {
                             __builtin_amdgcn_sched_group_barrier(0x100, NKC, 0);
+                            if constexpr (NKC == 1) {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                                for (int k = 0; k < 4; ++k) {
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                                }
+                                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NKC - 8, 0);
                             }
-                            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NKC - 8, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         };
                         const int ntl = gcount * 4;
@@ -406,16 +426,21 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
                         const float cv = j < c ? cbf[(size_t)brow * c + j] : 0.0f;
                         const float df = cv - q[j];
                         cvp[j] = q[j] + df;
-                        cvh[li][j] = cvp[j];
+                        if constexpr (MULTI) cvh[li][j] = cvp[j];
                     }
                     if (live) {
                         float *dst = cvf + ((size_t)l * p.tok_pad + t) * CVS;
+                        if constexpr (CVS == CP) {
 #pragma unroll
-                        for (int v = 0; v < CVS / 4; ++v)
-                            *reinterpret_cast<f32x4 *>(dst + 4 * v) = f32x4{4 * v < CP ? cvp[4 * v < CP ? 4 * v : 0] : 0.0f,
-                                                                             4 * v + 1 < CP ? cvp[4 * v + 1 < CP ? 4 * v + 1 : 0] : 0.0f,
-                                                                             4 * v + 2 < CP ? cvp[4 * v + 2 < CP ? 4 * v + 2 : 0] : 0.0f,
-                                                                             4 * v + 3 < CP ? cvp[4 * v + 3 < CP ? 4 * v + 3 : 0] : 0.0f};
+                            for (int j = 0; j < CP; ++j) dst[j] = cvp[j];      // a wave's 64 lanes: 64 x CP contiguous floats
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < CVS / 4; ++v)
+                                *reinterpret_cast<f32x4 *>(dst + 4 * v) = f32x4{4 * v < CP ? cvp[4 * v < CP ? 4 * v : 0] : 0.0f,
+                                                                                 4 * v + 1 < CP ? cvp[4 * v + 1 < CP ? 4 * v + 1 : 0] : 0.0f,
+                                                                                 4 * v + 2 < CP ? cvp[4 * v + 2 < CP ? 4 * v + 2 : 0] : 0.0f,
+                                                                                 4 * v + 3 < CP ? cvp[4 * v + 3 < CP ? 4 * v + 3 : 0] : 0.0f};
+                        }
                     }
                     // ---- later levels of this group see the level just applied
 #pragma unroll
@@ -444,8 +469,10 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
                     W_ACC(a_gram, t_e, t_f);
                 } else {
                     codes[li] = 0;
+                    if constexpr (MULTI) {
 #pragma unroll
-                    for (int j = 0; j < CP; ++j) cvh[li][j] = 0.0f;
+                        for (int j = 0; j < CP; ++j) cvh[li][j] = 0.0f;
+                    }
                 }
             });
             if (live && t < p.n_tokens) {
@@ -455,6 +482,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, 2) void gram_levels_wide_kernel(
             }
             // ---- projections of the later level groups see this group's levels
             W_T(t_m0);
+            if constexpr (MULTI)
             if (live)
                 for (int l2 = (lg + 1) * GL; l2 < p.levels; ++l2) {
                     const int o0 = (l2 / GL) * GP + (l2 % GL) * CP;

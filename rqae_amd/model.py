@@ -153,6 +153,7 @@ class RQAE(nn.Module):
         state["_gram"] = None
         state["_gram_ws"] = None
         state.pop("_gram_scaled", None)
+        state.pop("_gemma_inv", None)
         state["gram_options"] = None      # a ctypes struct: not picklable, and a per-process tuning choice anyway
         state.pop("_param_list", None)
         state.pop("_key_state", None)
@@ -616,6 +617,17 @@ class RQAE(nn.Module):
                 ws = self._gram_ws
                 if ws is None or ws.device != hs_llm.device or ws.numel() < need:
                     ws = self._gram_ws = torch.empty(need, dtype=torch.uint8, device=hs_llm.device)
+                if replace and self.num_quantizers <= 8:
+                    # ... and the way back folded into the reconstruction's stores: hs is patched in place, `quantized` never exists
+                    inv = self.__dict__.get("_gemma_inv")
+                    if inv is None or inv[0] is not final_norm.weight or inv[1] != final_norm.weight._version:
+                        inv = self.__dict__["_gemma_inv"] = (final_norm.weight, final_norm.weight._version,
+                                                             _native.gemma_inv_1pw(final_norm.weight))
+                    codes, _ = _native.encode_gram_gemma_patch(self.gram_packed_weights_scaled(final_norm.weight), self._dims(), hs_llm,
+                                                               inv[2], eps, self.num_quantizers, skip_bos, workspace=ws,
+                                                               options=self.__dict__.get("gram_options"))
+                    self.update_codebook_counts(codes)
+                    return
                 q_out, codes, inv_rms = _native.encode_gram_gemma(self.gram_packed_weights_scaled(final_norm.weight), self._dims(),
                                                                   hs_llm, eps, self.num_quantizers, workspace=ws,
                                                                   options=self.__dict__.get("gram_options"))

@@ -456,7 +456,7 @@ def test_arm_auto_switches_on_batch_size():
         assert torch.equal(auto(large)[0], gram(large)[0])
 
 
-@pytest.mark.parametrize("variant", ["fused", "pipelined", "first kernels", "lean chain, 8 waves", "first level chain"])
+@pytest.mark.parametrize("variant", ["fused", "pipelined", "first kernels", "lean chain, 8 waves", "first level chain", "streamed level chain"])
 def test_gram_kernel_variants(variant):
     """Every kernel selection of the arm (rqae_hip_gram_options, handed over per call) under the same Tier-2 bar, at a size that spans several
     tiles / passes and a ragged end; the defaults are what every other test in this file runs."""
@@ -468,7 +468,8 @@ def test_gram_kernel_variants(variant):
     sel = np.unique(np.concatenate([np.arange(0, n, 61), np.arange(n - 300, n)]))
     m.gram_options = {"fused": _native.gram_options(fused=1), "pipelined": _native.gram_options(pipe_chunk=16384),
                       "first kernels": _native.gram_options(proj=2, recon=1), "lean chain, 8 waves": _native.gram_options(lean_levels=1),
-                      "first level chain": _native.gram_options(lean_levels=0)}[variant]     # per call, no process-wide switch
+                      "first level chain": _native.gram_options(lean_levels=0),
+                      "streamed level chain": _native.gram_options(lean_levels=3)}[variant]     # per call, no process-wide switch
     for dt in (torch.bfloat16, torch.float16, torch.float32):
         q, idx, xs = run(m, x, dt)
         check_tier2(xs[sel], w, q[sel], idx[sel])
@@ -504,7 +505,7 @@ def test_operators_match_the_module_bit_for_bit():
         assert torch.equal(cv, cv2) and torch.equal(k, k2)
 
 
-class _Gemma2RMSNorm(torch.nn.Module):
+class Gemma2RMSNorm(torch.nn.Module):
     """HF Gemma2RMSNorm, the module behind Gemma2.norm (rqae/llm.py:65-66)."""
 
     def __init__(self, weight, eps=1e-6):
@@ -522,7 +523,7 @@ class _FakeGemma2LLM:
 
     def __init__(self, weight):
         inner = torch.nn.Module()
-        inner.norm = _Gemma2RMSNorm(weight)
+        inner.norm = Gemma2RMSNorm(weight)
         outer = torch.nn.Module()
         outer.model = inner
         self.model = outer
@@ -562,7 +563,8 @@ def test_gemma_hook_on_the_matrix_core_arm(dtype, B, S):
         torch.cuda.synchronize()
         return hs, st
 
-    hs_g, _ = run(mg_, False)                      # no store: the folded path (rqae_hip_encode_gram_gemma)
+    hs_g, _ = run(mg_, False)                      # no store: the folded path, in place (rqae_hip_encode_gram_gemma_patch)
+    assert "_gemma_inv" in mg_.__dict__            # ... and not the generic hook (model._gemma_final_norm goes by the norm's class name)
     hs_e, st_e = run(me_, True)                    # exact arm, with the store: normed / indices / quantized / new
     # the codes of the folded call: take them from a direct call of the entry point (the hook keeps none without a store)
     q_g, idx_g, rs_g = _native.encode_gram_gemma(mg_.gram_packed_weights_scaled(llm.model.model.norm.weight), mg_._dims(), hs0, 1e-6, 8)
@@ -576,15 +578,28 @@ def test_gemma_hook_on_the_matrix_core_arm(dtype, B, S):
     assert torch.equal(hs_g[:, 0], hs0[:, 0])
     same = (idx_g == st_e["indices"]).all(-1)
     a, b = hs_g.float()[same], hs_e.float()[same]
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
     if a.numel():
         scale = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
-        ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
         assert float(((a - b).abs() / scale).max()) <= ulp                       # at most one rounding step of the LLM dtype
         assert float((a != b).float().mean()) < 0.02                             # and nearly every element identical
+    # the in-place entry point the hook used (rqae_hip_encode_gram_gemma_patch): the same codes and 1/rms as the entry point that
+    # returns `quantized`, bit for bit (same projection and level kernels), and skip_bos = False patches the first rows too
+    hs_p = hs0.clone()
+    idx_p, rs_p = _native.encode_gram_gemma_patch(mg_.gram_packed_weights_scaled(llm.model.model.norm.weight), mg_._dims(), hs_p,
+                                                  _native.gemma_inv_1pw(llm.model.model.norm.weight), 1e-6, 8, False)
+    torch.cuda.synchronize()
+    assert torch.equal(idx_p, idx_g) and torch.equal(rs_p, rs_g)
+    assert torch.equal(hs_p[:, 1:], hs_g[:, 1:])
+    ref0 = ((q_g[:, 0] / (1.0 + llm.model.model.norm.weight.float())) / rs_g[:, 0, None]).to(dtype)
+    assert float(((hs_p[:, 0].float() - ref0.float()).abs() / ref0.float().abs().amax(-1, keepdim=True).clamp_min(1e-30)).max()) <= ulp
+    assert not torch.equal(hs_p[:, 0], hs0[:, 0])
     # with a store the hook takes the norm as its own kernel + forward on the matrix-core arm: same protocol, same codes
     hs_s, st_s = run(mg_, True)
     assert set(st_s) == {"original", "normed", "quantized", "indices", "new"}
-    assert (st_s["indices"] == idx_g).all(-1).float().mean().item() > 0.999
+    # (normed there is rounded to the LLM dtype before the projection, here it never is: a token in a few hundred sits close enough
+    #  to a tie for that to decide it)
+    assert int((st_s["indices"] != idx_g).any(-1).sum()) <= max(1, n // 300)
 
 
 def test_operators_see_weights_restacked_after_an_update():

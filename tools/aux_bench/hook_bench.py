@@ -1,4 +1,5 @@
-"""RQAE.hook(llm=gemma) per call: the matrix-core arm with the norm folded into its projection (rqae_hip_encode_gram_gemma), the
+"""RQAE.hook(llm=gemma) per call: the matrix-core arm with the norm folded into its projection and the way back folded into its
+reconstruction's stores (rqae_hip_encode_gram_gemma_patch: the layer output is patched in place), the
 exact arm's fused hook (rqae_hip_encode_gemma), and the generic hook (torch ops around forward) -- ms per hook call, fp16 hidden
 states, no store.  Run ON the GPU box:  python tools/aux_bench/hook_bench.py [--quick]"""
 import json
@@ -26,7 +27,7 @@ out = {}
 shapes = [(64, 128), (2048, 128)] if "--quick" in sys.argv else [(4, 128), (64, 128), (256, 128), (2048, 128)]
 for B, S in shapes:
     hs0 = (torch.randn(B, S, cfg["dim"], device="cuda") * 3).half()
-    for name, arm, fused in (("gram arm, folded norm", "gram", True), ("exact arm, fused", "exact", True), ("generic (torch ops + exact forward)", "exact", False)):
+    for name, arm, fused in (("gram arm, norm and way back folded", "gram", True), ("exact arm, fused", "exact", True), ("generic (torch ops + exact forward)", "exact", False)):
         fn = models[arm].hook(llm=llm, fused=fused)
         hs = hs0.clone()
         reps = 30 if B * S >= 100000 else 50

@@ -1726,7 +1726,19 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
         pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
         pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
-        if (!levels_resident_ok(g)) {
+        if (!levels_resident_ok(g) && g.CP == 4 && c == 4 && g.shared_cb && g.NKC == 1 && tuning().lev2 == 3) {
+            // variant (lean_levels = 3) for a narrow codebook too large for LDS (C5: K 4096, depth 32): gram_wide.hpp's streamed form
+            // -- 8 computing waves + 2 loader waves, scan maxima one tile late -- writing the operand rows gram_reconstruct_kernel
+            // reads.  Measured at C5, 262 144 tokens: 2.42 ms against gram_levels_stream_kernel's 2.31 (60 cycles per matrix
+            // instruction and wave in the scan, two waves per SIMD), so the default stays the older kernel
+            const int nw = 8;
+            const size_t lds = wide_levels_lds_bytes(g.NKC, nw);
+            long long nb = (pb.ntiles + nw - 1) / nw;
+            if (nb > ncu) nb = ncu;
+            G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_levels_wide_kernel<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((gram_levels_wide_kernel<4, 8, true>), dim3((unsigned)nb), dim3((nw + W_NWL) * 64), lds, s, pb);
+            G_TRY(hipGetLastError());
+        } else if (!levels_resident_ok(g)) {
             // persistent: a workgroup's waves walk the ring together.  8 waves per workgroup halve the L2 -> LDS refill per token;
             // 4 when 8 would leave CUs without a workgroup
             const int nw = (pb.ntiles + SL_NW - 1) / SL_NW >= ncu ? SL_NW : 4;

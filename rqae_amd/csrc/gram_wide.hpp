@@ -41,7 +41,7 @@ template <int CP> struct WideGeom {
 
 __host__ __device__ inline size_t wide_levels_lds_bytes(int nkc, int nw) { return (size_t)W_NST * W_STT * nkc * 1024 + (size_t)nw * 4096; }   // nw = computing waves
 
-// p.cvimg is used as float planes [levels][tok_pad][16]
+// p.cvimg is used as float planes [levels][tok_pad][CVS] (or as operand rows: IMG below)
 // (second launch bound: a budget of 256 registers, so the MFMA accumulators stay in VGPRs.  With the 512 registers one wave per SIMD
 //  may take, hipcc parks them in AGPRs and pays four v_accvgpr_read + s_nop per accumulator before the maxima can read them.)
 // Waves 0 .. NW-1 compute; waves NW, NW+1 only move the image: a global_load_lds occupies its wave's issue for 100-185 cycles
@@ -55,6 +55,9 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
     using G = WideGeom<CP>;
     constexpr int GL = G::GL, GP = G::GP, NKC = G::NKC, GB = G::GB, STAGE = G::STAGE, CVS = G::CVS;
     static_assert(NKC == 1 || NKC == 3, "one or three k-steps per cosine contraction");
+    // IMG: the straight-through values leave as the bf16-piece operand rows gram_reconstruct_kernel reads (deep chains of a narrow
+    // codebook: C5), not as fp32 planes (gram_fused_kernel MODE 3 / gram_recon_wide_kernel)
+    constexpr bool IMG = MULTI && CP == 4;
     static_assert((W_STT * NKC) % W_NWL == 0, "every loader wave issues the same number of pieces per stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
@@ -428,7 +431,35 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
                         cvp[j] = q[j] + df;
                         if constexpr (MULTI) cvh[li][j] = cvp[j];
                     }
-                    if (live) {
+                    if constexpr (IMG) {
+                        // operand rows of gram_reconstruct_kernel ([k-step][tok_pad][16 dwords]; slot (li CP + j) 6 + term, two bf16 per
+                        // dword: hi|mid, hi|lo, hi|mid): a level's 12 dwords are three 16-byte pieces, none of which straddles a row
+                        if (live) {
+                            unsigned dw[3 * CP];
+#pragma unroll
+                            for (int j = 0; j < CP; ++j) {
+                                unsigned h, m, lo;
+                                split3(cvp[j], h, m, lo);
+                                dw[3 * j] = pack_hi16(h, m);
+                                dw[3 * j + 1] = pack_hi16(h, lo);
+                                dw[3 * j + 2] = dw[3 * j];
+                            }
+#pragma unroll
+                            for (int v = 0; v < 3 * CP / 4; ++v) {
+                                const int dpos = 3 * CP * li + 4 * v;
+                                unsigned *dst = p.cvimg + ((size_t)(lg * G::NKG + dpos / 16) * p.tok_pad + t) * 16 + dpos % 16;
+                                *reinterpret_cast<u32x4 *>(dst) = u32x4{dw[4 * v], dw[4 * v + 1], dw[4 * v + 2], dw[4 * v + 3]};
+                            }
+                            if (l == p.levels - 1) {
+                                // the rest of the last k-step the chain reaches: zeros (stale bytes never meet a matrix instruction)
+#pragma unroll
+                                for (int dpos = 3 * CP * (li + 1); dpos % 16 != 0; dpos += 4) {
+                                    unsigned *dst = p.cvimg + ((size_t)(lg * G::NKG + dpos / 16) * p.tok_pad + t) * 16 + dpos % 16;
+                                    *reinterpret_cast<u32x4 *>(dst) = u32x4{0u, 0u, 0u, 0u};
+                                }
+                            }
+                        }
+                    } else if (live) {
                         float *dst = cvf + ((size_t)l * p.tok_pad + t) * CVS;
                         if constexpr (CVS == CP) {
 #pragma unroll

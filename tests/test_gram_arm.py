@@ -237,6 +237,16 @@ def test_gram_c5_streamed_codebook_depth_32():
         check_tier2(xs, w, q, idx)
     q, idx, xs = run(m, x[:300], torch.float32, max_layers=19)
     check_tier2(xs, w, q, idx, levels=19)
+    # the other streamed level chain (gram_wide.hpp's form with loader waves, writing the same operand rows): same bar, and a
+    # depth that ends inside a k-step of the reconstruction's operand rows
+    m.gram_options = _native.gram_options(lean_levels=3)
+    q, idx, xs = run(m, x, torch.bfloat16)
+    check_tier2(xs, w, q, idx)
+    q, idx, xs = run(m, x[:300], torch.float32, max_layers=19)
+    check_tier2(xs, w, q, idx, levels=19)
+    q, idx, xs = run(m, x[:300], torch.float32, max_layers=5)
+    check_tier2(xs, w, q, idx, levels=5)
+    m.gram_options = None
     # a batch that fills the chip
     me_ = make_model(cfg, w, "exact")
     n = 65536

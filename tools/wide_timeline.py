@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", type=int, default=65536)
+    ap.add_argument("--config", default="C4", help="C4 (c 13, K 8192, depth 16) or C5 (c 4, K 4096, depth 32)")
     ap.add_argument("--define", action="append", default=[])
     ap.add_argument("--build-only", action="store_true")
     ap.add_argument("--no-build", action="store_true")
@@ -37,7 +38,7 @@ def main():
     import numpy as np
     import torch
     from rqae_amd import RQAE, _native, synth
-    cfg = synth.CONFIGS["C4"]
+    cfg = synth.CONFIGS[args.config]
     w = synth.weights(1, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
     m = RQAE(**cfg, arm="gram").eval()
     m.load_state_dict(synth.state_dict_from_weights(w))
@@ -61,7 +62,11 @@ def main():
     tot = a[:, 0].mean()
     for i, nm in enumerate(names):
         print(f"  {nm:26s} {a[:, i].mean():12.0f} cycles per wave  ({100 * a[:, i].mean() / tot:5.1f} %)   min {a[:, i].min():.0f} max {a[:, i].max():.0f}")
-    print(f"  scan per level {a[:, 3].mean() / cfg['num_quantizers']:.0f} cycles = {a[:, 3].mean() / cfg['num_quantizers'] / (512 * 12):.1f} cycles per matrix instruction")
+    K, c = cfg["codebook_size"] ** cfg["codebook_dim"], cfg["codebook_dim"]
+    per_tile = (K // 16) * (3 if c > 5 else 1) * 4           # matrix instructions per level and 64-token tile
+    tiles = nw / len(a)                                       # 64-token tiles per (persistent) wave
+    print(f"  {len(a)} waves, {tiles:.2f} tiles each; scan per level and tile {a[:, 3].mean() / cfg['num_quantizers'] / tiles:.0f} cycles = "
+          f"{a[:, 3].mean() / cfg['num_quantizers'] / tiles / per_tile:.1f} cycles per matrix instruction")
 
 
 if __name__ == "__main__":

@@ -1364,7 +1364,11 @@ bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g
 bool levels_stream_ok(const Geom &g) { return g.shared_cb && g.NKC == 1 && g.CP <= 5; }
 
 // wide codebook vectors (6 <= c <= 13: three k-steps per cosine contraction, four levels per group): gram_wide.hpp
-bool levels_wide_ok(const Geom &g) { return g.shared_cb && g.CP == 13 && g.NKC == 3 && g.d % 128 == 0 && g.NLG <= 4; }
+bool levels_wide_ok(const Geom &g) { return g.CP == 13 && g.NKC == 3 && g.d % 128 == 0 && g.NLG <= 4 && (g.shared_cb || g.K % 16 == 0); }
+
+// one codebook PER LEVEL (any quantization_method but the FSQ lattices: rqae/model.py:46-54): nothing stays resident across levels,
+// so every level streams its own image -- gram_wide.hpp's kernel for c <= 5 too (whole row tiles: its rescoring reads past K otherwise)
+bool levels_free_ok(const Geom &g) { return !g.shared_cb && g.K % 16 == 0 && ((g.CP <= 5 && g.NKC == 1) || levels_wide_ok(g)); }
 
 // the one-kernel form: one level group, whole chunks of 2 k-steps, everything resident fits the CU's 160 KiB of LDS
 bool fused_shape_ok(const Geom &g, int levels)
@@ -1419,7 +1423,7 @@ int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared)
 {
     if (!gram_shape_ok(d, c, K, L)) return 0;
     const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
-    return ((g.CP <= 5 && levels_resident_ok(g)) || levels_stream_ok(g) || levels_wide_ok(g)) ? 1 : 0;
+    return ((g.CP <= 5 && levels_resident_ok(g)) || levels_stream_ok(g) || (g.shared_cb && levels_wide_ok(g)) || levels_free_ok(g)) ? 1 : 0;
 }
 
 size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared)
@@ -1726,7 +1730,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
         pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
         pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
-        if (!levels_resident_ok(g) && g.CP == 4 && c == 4 && g.shared_cb && g.NKC == 1 && tuning().lev2 == 3) {
+        if (g.CP <= 5 && g.NKC == 1 && (!g.shared_cb || (!levels_resident_ok(g) && g.CP == 4 && c == 4 && tuning().lev2 == 3))) {
+            // per-level codebooks (levels_free_ok): every level streams its own image through the ring.  Also a
             // variant (lean_levels = 3) for a narrow codebook too large for LDS (C5: K 4096, depth 32): gram_wide.hpp's streamed form
             // -- 8 computing waves + 2 loader waves, scan maxima one tile late -- writing the operand rows gram_reconstruct_kernel
             // reads.  Measured at C5, 262 144 tokens: 2.42 ms against gram_levels_stream_kernel's 2.31 (60 cycles per matrix
@@ -1735,9 +1740,13 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             const size_t lds = wide_levels_lds_bytes(g.NKC, nw);
             long long nb = (pb.ntiles + nw - 1) / nw;
             if (nb > ncu) nb = ncu;
-            G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_levels_wide_kernel<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((gram_levels_wide_kernel<4, 8, true>), dim3((unsigned)nb), dim3((nw + W_NWL) * 64), lds, s, pb);
-            G_TRY(hipGetLastError());
+            auto go = [&](auto kern) -> int {
+                G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3((nw + W_NWL) * 64), lds, s, pb);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            if (int rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 8, true>) : go(gram_levels_wide_kernel<5, 8, true>)) return rc;
         } else if (!levels_resident_ok(g)) {
             // persistent: a workgroup's waves walk the ring together.  8 waves per workgroup halve the L2 -> LDS refill per token;
             // 4 when 8 would leave CUs without a workgroup

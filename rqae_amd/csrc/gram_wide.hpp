@@ -39,6 +39,20 @@ template <int CP> struct WideGeom {
                                                                    // one-group reconstruction, gram_fused_kernel MODE 3, reads) or 16
 };
 
+// Cutting dwords [d0, d1) of a row into aligned stores of 4, 2 or 1 dwords, greedily from d0: the width of the piece that STARTS at
+// dword d, or 0 when d lies inside a piece that started earlier.
+__host__ __device__ constexpr int wide_piece_width(int d0, int d1, int d)
+{
+    int pos = d0;
+    while (pos < d1) {
+        const int w = (pos % 4 == 0 && pos + 4 <= d1) ? 4 : (pos % 2 == 0 && pos + 2 <= d1) ? 2 : 1;
+        if (pos == d) return w;
+        if (pos > d) return 0;
+        pos += w;
+    }
+    return 0;
+}
+
 __host__ __device__ inline size_t wide_levels_lds_bytes(int nkc, int nw) { return (size_t)W_NST * W_STT * nkc * 1024 + (size_t)nw * 4096; }   // nw = computing waves
 
 // p.cvimg is used as float planes [levels][tok_pad][CVS] (or as operand rows: IMG below)
@@ -57,13 +71,13 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
     static_assert(NKC == 1 || NKC == 3, "one or three k-steps per cosine contraction");
     // IMG: the straight-through values leave as the bf16-piece operand rows gram_reconstruct_kernel reads (deep chains of a narrow
     // codebook: C5), not as fp32 planes (gram_fused_kernel MODE 3 / gram_recon_wide_kernel)
-    constexpr bool IMG = MULTI && CP == 4;
+    constexpr bool IMG = MULTI && CP <= 5;
     static_assert((W_STT * NKC) % W_NWL == 0, "every loader wave issues the same number of pieces per stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
     const int c = p.c;
     char *xch = smem + W_NST * STAGE + wave * 4096;
-    const float *cbf = p.cb_f32;                       // global (L2): K x c fp32, + 64 zero rows
+    const float *cbf0 = p.cb_f32;                      // global (L2): [1 or L] x K x c fp32, + 64 zero rows at the end
     float *cvf = reinterpret_cast<float *>(p.cvimg);
     const int nstage = (p.KTP + W_STT - 1) / W_STT;    // KTP is a multiple of 4; W_STT of 4 too: stages hold whole groups of 4 row tiles
     constexpr int PW = (W_STT * NKC) / W_NWL;          // pieces per loader wave and stage
@@ -94,6 +108,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
         const int lw = wave - NW;
         constexpr int NR = 3;                          // register sets: loads of up to two stages in flight behind the one being written
         u32x4 R[NR][PW];
+        const char *img_l = img;                      // the image of the level being streamed (per-level codebooks: one each)
         auto gload = [&](int s, u32x4 (&r)[PW]) {
 #ifdef W_NO_LOAD   /* tools build, timing only (wrong results): the loaders keep the barriers and move nothing */
             return;
@@ -103,7 +118,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
                 const int pc = lw * PW + i;
                 size_t off = ((size_t)stage_of(s) * W_STT * NKC + pc) * 1024;
                 off = off < img_bytes ? off : img_bytes - 1024;
-                r[i] = *reinterpret_cast<const u32x4 *>(img + off + lane * 16);
+                r[i] = *reinterpret_cast<const u32x4 *>(img_l + off + lane * 16);
             }
         };
         auto lwrite = [&](int s, const u32x4 (&r)[PW]) {
@@ -150,6 +165,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
                     }
                 }
                 __builtin_amdgcn_s_barrier();          // every wave has left the last stages: the ring is free
+                if (!p.shared_cb) img_l = img + (size_t)(l + 1 < p.levels ? l + 1 : 0) * img_bytes;
                 prologue();                            // the next level's (or tile's) first stages, behind the serial part
             }
         return;
@@ -197,6 +213,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
                 const int l = lg * GL + li;
                 if (l < p.levels) {
                     W_T(t_a);
+                    const float *cbf = p.shared_cb ? cbf0 : cbf0 + (size_t)l * p.K * c;      // this level's rows
                     float q[CP];
 #pragma unroll
                     for (int j = 0; j < CP; ++j) q[j] = Q[li][j];
@@ -444,19 +461,37 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
                                 dw[3 * j + 1] = pack_hi16(h, lo);
                                 dw[3 * j + 2] = dw[3 * j];
                             }
-#pragma unroll
-                            for (int v = 0; v < 3 * CP / 4; ++v) {
-                                const int dpos = 3 * CP * li + 4 * v;
+                            // the level's 3 CP dwords start at dword 3 CP li of the group row: the widest aligned stores that fit (12
+                            // dwords at CP 4 are three 16-byte pieces; 15 at CP 5 fall as the level's position has it), none across a
+                            // k-step row (16 dwords); then zeros up to the end of the k-step after the chain's or the group's last level
+                            auto put = [&](int dpos, auto w_c, unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+                                constexpr int W = decltype(w_c)::value;
+                                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
                                 unsigned *dst = p.cvimg + ((size_t)(lg * G::NKG + dpos / 16) * p.tok_pad + t) * 16 + dpos % 16;
-                                *reinterpret_cast<u32x4 *>(dst) = u32x4{dw[4 * v], dw[4 * v + 1], dw[4 * v + 2], dw[4 * v + 3]};
-                            }
-                            if (l == p.levels - 1) {
-                                // the rest of the last k-step the chain reaches: zeros (stale bytes never meet a matrix instruction)
-#pragma unroll
-                                for (int dpos = 3 * CP * (li + 1); dpos % 16 != 0; dpos += 4) {
-                                    unsigned *dst = p.cvimg + ((size_t)(lg * G::NKG + dpos / 16) * p.tok_pad + t) * 16 + dpos % 16;
-                                    *reinterpret_cast<u32x4 *>(dst) = u32x4{0u, 0u, 0u, 0u};
-                                }
+                                if constexpr (W == 4) *reinterpret_cast<u32x4 *>(dst) = u32x4{a0, a1, a2, a3};
+                                else if constexpr (W == 2) *reinterpret_cast<u32x2 *>(dst) = u32x2{a0, a1};
+                                else *dst = a0;
+                            };
+                            constexpr int D0 = 3 * CP * li, D1 = 3 * CP * (li + 1);
+                            static_for<0, 3 * CP>([&](auto i_c) {
+                                constexpr int i = decltype(i_c)::value, dpos = D0 + i;
+                                // greedy cut: this dword starts a piece iff no wider piece that began earlier covers it
+                                constexpr int w = wide_piece_width(D0, D1, dpos);
+                                if constexpr (w == 4) put(dpos, std::integral_constant<int, 4>{}, dw[i], dw[i + 1], dw[i + 2], dw[i + 3]);
+                                else if constexpr (w == 2) put(dpos, std::integral_constant<int, 2>{}, dw[i], dw[i + 1], 0u, 0u);
+                                else if constexpr (w == 1) put(dpos, std::integral_constant<int, 1>{}, dw[i], 0u, 0u, 0u);
+                            });
+                            constexpr int DE = (D1 + 15) / 16 * 16;
+                            if (l == p.levels - 1 || li == GL - 1) {
+                                static_for<0, 16>([&](auto i_c) {
+                                    constexpr int dpos = D1 + decltype(i_c)::value;
+                                    if constexpr (dpos < DE) {
+                                        constexpr int w = wide_piece_width(D1, DE, dpos);
+                                        if constexpr (w == 4) put(dpos, std::integral_constant<int, 4>{}, 0u, 0u, 0u, 0u);
+                                        else if constexpr (w == 2) put(dpos, std::integral_constant<int, 2>{}, 0u, 0u, 0u, 0u);
+                                        else if constexpr (w == 1) put(dpos, std::integral_constant<int, 1>{}, 0u, 0u, 0u, 0u);
+                                    }
+                                });
                             }
                         }
                     } else if (live) {

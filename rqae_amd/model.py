@@ -129,6 +129,7 @@ class RQAE(nn.Module):
         self._packed = None  # .to()/.cuda()/.float() move or retype the parameters
         self._gram = None
         self.__dict__.pop("_gram_scaled", None)
+        self.__dict__.pop("_gram_free", None)
         self._gram_ws = None
         self._drop_metadata_cache()
         return super()._apply(fn, *args, **kwargs)
@@ -137,6 +138,7 @@ class RQAE(nn.Module):
         self._packed = None
         self._gram = None
         self.__dict__.pop("_gram_scaled", None)
+        self.__dict__.pop("_gram_free", None)
         self._drop_metadata_cache()
         return super().load_state_dict(*args, **kwargs)
 
@@ -153,6 +155,7 @@ class RQAE(nn.Module):
         state["_gram"] = None
         state["_gram_ws"] = None
         state.pop("_gram_scaled", None)
+        state.pop("_gram_free", None)
         state.pop("_gemma_inv", None)
         state["gram_options"] = None      # a ctypes struct: not picklable, and a per-process tuning choice anyway
         state.pop("_param_list", None)
@@ -216,6 +219,7 @@ class RQAE(nn.Module):
         self._packed = None
         self._gram = None
         self.__dict__.pop("_gram_scaled", None)
+        self.__dict__.pop("_gram_free", None)
         self.__dict__.pop("_param_list", None)
         self.__dict__.pop("_key_state", None)
 
@@ -272,9 +276,10 @@ class RQAE(nn.Module):
 
     # ------------------------------------------------------------ matrix-core arm
     def _use_gram(self, n_tokens: int, levels: int) -> bool:
-        if self.arm == "exact" or self.quantization_method not in _FSQ_METHODS:
+        if self.arm == "exact":
             return False
-        ok = _native.gram_supported(self._dims(), True)
+        # FSQ lattices: one codebook for every level; any other method: one per level, streamed level by level
+        ok = _native.gram_supported(self._dims(), self.quantization_method in _FSQ_METHODS)
         if self.arm == "gram":
             if not ok:
                 raise RuntimeError(f"rqae_amd: arm='gram' does not serve shape (d, c, K, L) = {self._dims()} "
@@ -322,8 +327,31 @@ class RQAE(nn.Module):
         ws = self._gram_ws
         if ws is None or ws.device != x2d.device or ws.numel() < need:
             ws = self._gram_ws = torch.empty(need, dtype=torch.uint8, device=x2d.device)
-        return _native.encode_gram(self.gram_packed_weights(), self._dims(), True, x2d, levels,
+        packed, shared = self._gram_packed_for_encode(levels)
+        return _native.encode_gram(packed, self._dims(), shared, x2d, levels,
                                    want_recon=want_recon, workspace=ws, options=self.__dict__.get("gram_options"))
+
+    def _gram_packed_for_encode(self, levels: int):
+        """(block, codebook_shared) for one call on the matrix-core arm.  FSQ lattices: the cached block.  Any other method
+        renormalises all codebooks in place once per level (rqae/model.py:196 -> 126-131), as ``_packed_for_encode`` spells out;
+        the per-level snapshots are packed with one codebook per level, and the block is kept for as long as the snapshots come
+        out the same (renormalising unit rows reaches a fixed point after a call or two)."""
+        if self.quantization_method in _FSQ_METHODS:
+            return self.gram_packed_weights(), True
+        with torch.no_grad():
+            used = self.codebook.data.detach().float().clone()
+            for l in range(levels):
+                self.normalize_codebooks()
+                used[l] = self.codebook.data[l]
+            self.__dict__["_codebook_used"] = used[:levels].clone()
+            key = self._weights_key()
+            ent = self.__dict__.get("_gram_free")
+            if ent is None or ent[0] != key or ent[1].shape != used.shape or not torch.equal(ent[1], used):
+                if not torch.isfinite(used).all():
+                    raise RuntimeError("rqae_amd: codebook contains non-finite values")
+                w_in, b_in, w_out, b_out = self._stacked()
+                ent = self.__dict__["_gram_free"] = (key, used, _native.gram_pack(w_in, b_in, used.contiguous(), w_out, b_out, False))
+        return ent[2], False
 
     # ------------------------------------------------------------- small mirrors
     def update_codebook_counts(self, indices):
@@ -537,7 +565,8 @@ class RQAE(nn.Module):
         if idx.dtype not in (torch.int64, torch.int32, torch.uint16):
             idx = idx.long()
         idx = idx.contiguous()
-        if all(keep) and self._use_gram(B * S, NQ) and _native.decode_gram_supported(self._dims(), True, NQ):
+        if (all(keep) and self.quantization_method in _FSQ_METHODS and self._use_gram(B * S, NQ)
+                and _native.decode_gram_supported(self._dims(), True, NQ)):
             # the matrix-core arm's reconstruction kernel fed by the codes: same sum within 1e-6 relative, HBM-write-bound
             out = _native.decode_gram(self.gram_packed_weights(), self._dims(), True, idx)
         else:
@@ -608,7 +637,8 @@ class RQAE(nn.Module):
             fold = (store is None and hs_llm.shape[-1] == self._dim and self.quantization_method in _FSQ_METHODS
                     and n_tok > 8 * torch.cuda.get_device_properties(hs_llm.device).multi_processor_count
                     and _native.encode_gemma_supported(self._dims()))
-            fold_gram = (store is None and hs_llm.shape[-1] == self._dim and self._use_gram(n_tok, self.num_quantizers)
+            fold_gram = (store is None and hs_llm.shape[-1] == self._dim and self.quantization_method in _FSQ_METHODS
+                         and self._use_gram(n_tok, self.num_quantizers)
                          and _native.encode_gram_gemma_supported(self._dims(), hs_llm.dtype))
             if fold_gram:
                 # the matrix-core arm (self.arm = "gram" / "auto"): 1 + w folded into the W_in image, sum(hs^2) taken in the

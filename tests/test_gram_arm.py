@@ -268,6 +268,40 @@ def test_gram_c5_streamed_codebook_depth_32():
     print(f"gram arm, C5 depth 32, {n} tokens: {len(rows)} low-margin tokens differ from the exact arm, all adjudicated")
 
 
+@pytest.mark.parametrize("shape", [dict(dim=512, codebook_dim=5, codebook_size=1024, num_quantizers=8),
+                                   dict(dim=2304, codebook_dim=4, codebook_size=2048, num_quantizers=19),
+                                   dict(dim=512, codebook_dim=5, codebook_size=592, num_quantizers=11),
+                                   dict(dim=512, codebook_dim=3, codebook_size=256, num_quantizers=9),
+                                   dict(dim=512, codebook_dim=8, codebook_size=1024, num_quantizers=6)])
+def test_gram_per_level_codebooks(shape):
+    """Any quantization_method but the FSQ lattices keeps one learned codebook PER LEVEL and renormalises all of them in place once
+    per level (rqae/model.py:46-54, 126-131, 196).  On the matrix-core arm every level streams its own image through LDS
+    (csrc/gram_wide.hpp, for c <= 5 too).  Tier 2 against the oracle on the rows each level really saw (`_codebook_used`, as the
+    exact arm's test_generic_shape_free_codebook does), the codes-only call, a shallower call, and the exact arm on the same rows."""
+    cfg = dict(shape, quantization_method="vq")
+    w = synth.weights(77, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], free_codebook_rows=cfg["codebook_size"])
+    m, me_ = make_model(cfg, w, "gram"), make_model(cfg, w, "exact")
+    assert m._use_gram(100, cfg["num_quantizers"])
+    n = 5000 + 13
+    x = synth.activations(41, n, cfg["dim"])
+    for dt in (torch.float32, torch.bfloat16):
+        q, idx, xs = run(m, x, dt)
+        used = m._codebook_used.cpu().numpy()
+        assert idx.max() < cfg["codebook_size"]
+        check_tier2(xs, dict(w, codebook=used), q, idx)
+        with torch.inference_mode():
+            only = m.encode(torch.from_numpy(x).to(DEV).to(dt).view(1, n, -1))
+        assert np.array_equal(only.cpu().numpy().reshape(n, -1), idx)
+    # the exact arm on the same parameters: its per-level snapshots are the same rows, its codes the same up to low margins
+    qe, ie, _ = run(me_, x, torch.bfloat16)
+    # (this module has been through more calls, hence more renormalisations: its rows may sit an ulp from the other's)
+    assert np.abs(me_._codebook_used.cpu().numpy() - m._codebook_used.cpu().numpy()).max() < 1e-6
+    assert (ie != idx).any(axis=1).sum() <= max(2, n // 500)
+    lv = max(1, cfg["num_quantizers"] // 2 + 1)
+    q3, i3, xs = run(m, x[:700], torch.float32, max_layers=lv)
+    check_tier2(xs, dict(w, codebook=m._codebook_used.cpu().numpy()), q3, i3, levels=lv)
+
+
 def test_gram_c4_wide_codebook_depth_16():
     """BASELINE configs[3] as stated: d 3584, c 13, K 8192 = 2^13, depth 16 on the matrix cores (csrc/gram_wide.hpp: three k-steps
     per cosine contraction, the 1.5 MB codebook image streamed through LDS, four level groups of four levels, reconstruction with

@@ -1,6 +1,9 @@
 """Forward of a named BASELINE config on both arms, with the matrix-core arm's per-kernel times.
 
-    python tools/aux_bench/config_bench.py C5 65536 [--levels N] [--dtype bf16|f32]
+    python tools/aux_bench/config_bench.py C5 65536 [--levels N] [--dtype bf16|f32] [--free-codebooks]
+
+--free-codebooks: the config's shape with one learned codebook per level (quantization_method "vq", K rows each) instead of the
+shared FSQ lattice.
 """
 import argparse
 import json
@@ -29,11 +32,18 @@ ap.add_argument("config")
 ap.add_argument("tokens", type=int)
 ap.add_argument("--levels", type=int, default=0)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--free-codebooks", action="store_true")
 a = ap.parse_args()
 cfg = dict(synth.CONFIGS[a.config])
 if a.levels:
     cfg["num_quantizers"] = a.levels
-w = synth.weights(1, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+if a.free_codebooks:
+    rows = cfg["codebook_size"] ** cfg["codebook_dim"]
+    cfg.update(codebook_size=rows, quantization_method="vq")
+    w = synth.weights(1, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], free_codebook_rows=rows)
+else:
+    w = synth.weights(1, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+shared = not a.free_codebooks
 out = {"config": a.config, **cfg, "tokens": a.tokens, "dtype": a.dtype}
 x = torch.randn(1, a.tokens, cfg["dim"], device="cuda")
 x = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
@@ -42,7 +52,7 @@ for arm in ("exact", "gram"):
     m.load_state_dict(synth.state_dict_from_weights(w))
     m = m.to("cuda")
     K = m.codebook.shape[1]
-    if arm == "gram" and not _native.gram_supported(m._dims(), True):
+    if arm == "gram" and not _native.gram_supported(m._dims(), shared):
         out["gram"] = "not served"
         continue
     ms = timed(lambda: m(x))
@@ -50,6 +60,8 @@ for arm in ("exact", "gram"):
     if arm == "exact":
         out[arm]["kernel"] = _native.kernel_info(cfg["dim"], cfg["codebook_dim"], K, cfg["num_quantizers"])
     else:
+        if not shared:
+            continue
         ph = _native.encode_gram_phases(m.gram_packed_weights(), m._dims(), x.view(-1, cfg["dim"]), cfg["num_quantizers"])
         out[arm]["kernel_ms"] = {"project": round(ph[0], 3), "levels": round(ph[1], 3), "reconstruct": round(ph[2], 3)}
 print(json.dumps(out))

@@ -216,9 +216,13 @@ size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_token
  *   fused       1: one persistent kernel (projection + level chain + reconstruction per 256-token tile)        (0)
  *   proj        3: LDS-DMA projection kernel, 2: register-pipelined, 1: first form                               (3)
  *   recon       2: token-stationary reconstruction with 512-byte store rows, 1: weights-stationary               (2)
- *   lean_levels level chain of a single level group (levels <= 8): 2 = fp32 straight-through values handed to the
+ *   lean_levels the level chain.  4 = for a codebook that rqae_hip_gram_pack found to be an FSQ lattice ({linspace(-1, 1, n)}^c,
+ *               rows of unit length or plain: rqae/model.py:63-72) the lattice form -- the rows that can win follow from the
+ *               signs and the order of |projection| (6 of 1024 at n = 4, c = 5), each scored like the scan's rescoring scores
+ *               a row; no scan, no LDS -- and for any other codebook the scan kernel 2 names.  0..3 name a scan kernel and
+ *               switch the lattice form off: 2 = (one level group, levels <= 8) fp32 straight-through values handed to the
  *               reconstruction kernel, 16 waves per workgroup, tables resident in LDS; 1 = the same with 8 waves;
- *               0 = the first form; 3 = the streamed form (codebook image through a 24 KB ring by loader waves)     (2)
+ *               0 = the first form; 3 = the streamed form (codebook image through a 24 KB ring by loader waves)     (4)
  *   pipe_chunk  > 0: passes of that many tokens, reconstruction of pass i on a second stream beside pass i+1    (0) */
 typedef struct rqae_hip_gram_options {
     int32_t size;

@@ -20,6 +20,7 @@
 // Translation unit of librqae_hip.so (built by __graft_entry__.py); C ABI at the bottom, declared in
 // include/rqae_hip.h.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -139,7 +140,10 @@ GLayout make_glayout(const Geom &g)
 }
 
 struct GHeader {
-    int magic, d, c, K, L, shared_cb, pad[58];
+    int magic, d, c, K, L, shared_cb;
+    int lattice_n;            // n >= 2: the shared codebook is the FSQ lattice {linspace(-1, 1, n)}^c (gram_pack_lattice_kernel); else 0
+    int lattice_miss[2];      // scratch of that check: rows that are not the unit-length lattice row / not the plain lattice row
+    int pad[55];
 };
 static_assert(sizeof(GHeader) == 256, "header");
 
@@ -298,6 +302,35 @@ __global__ void gram_pack_gram_kernel(Geom g, const float *w_in, const float *b_
             __syncthreads();
         }
     }
+}
+
+// Is the shared codebook the FSQ lattice (gram_wide.hpp, "FSQ lattice")?  Row k has digits k / n^(c-1-j) % n, coordinate values
+// -1 + 2 digit / (n - 1), every row scaled to unit length (the zero row of an odd n stays zero) or every row left as it is.  One
+// thread per row, values in double, 1e-6 absolute (the stored rows are those doubles rounded to fp32: 6e-8).
+__global__ void gram_pack_lattice_kernel(const float *codebook, int K, int c, int n, GHeader *hdr)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double v[GRAM_MAX_C], ss = 0.0;
+    int rem = k;
+    for (int j = c - 1; j >= 0; --j) {
+        v[j] = -1.0 + 2.0 * (double)(rem % n) / (double)(n - 1);
+        rem /= n;
+        ss += v[j] * v[j];
+    }
+    const double inv = ss > 0.0 ? 1.0 / sqrt(ss) : 1.0;
+    bool unit = true, plain = true;
+    for (int j = 0; j < c; ++j) {
+        const double x = (double)codebook[(size_t)k * c + j];
+        unit = unit && fabs(x - v[j] * inv) <= 1e-6;
+        plain = plain && fabs(x - v[j]) <= 1e-6;
+    }
+    if (!unit) hdr->lattice_miss[0] = 1;
+    if (!plain) hdr->lattice_miss[1] = 1;
+}
+__global__ void gram_pack_lattice_verdict_kernel(GHeader *hdr)
+{
+    if (hdr->lattice_miss[0] && hdr->lattice_miss[1]) hdr->lattice_n = 0;
 }
 
 // codebook image: fragment (lcb, tile, ks) = A operand: lane 16g+r holds codebook row 16 tile + r, slots
@@ -744,6 +777,7 @@ struct LevParams {
     long long *idx;           // [n_tokens][levels]
     long long n_tokens, tok_pad, ntiles;
     int levels, L, K, KTP, c, shared_cb;
+    const int *lat_flag;      // the block's lattice word (GHeader::lattice_n: n >= 2 when the codebook is an FSQ lattice), or NULL
 };
 
 // One wave = 64 tokens, one token per lane for everything in c-space; for the cosine contraction the wave's
@@ -754,6 +788,7 @@ struct LevParams {
 template <int CP, int NW, bool MULTI>
 __global__ __launch_bounds__(NW * 64) void gram_levels_kernel(LevParams p)
 {
+    if (p.lat_flag && *reinterpret_cast<const volatile int *>(p.lat_flag) >= 2) return;      // the lattice form ran (gram_wide.hpp)
     constexpr int GL = CP <= 8 ? 8 : 4;
     constexpr int GP = ((GL * CP + 15) / 16) * 16;
     constexpr int GS = ((6 * CP * GL + 31) / 32) * 32;
@@ -1248,6 +1283,7 @@ struct Tuning {
     int cap_ab;          // pipelined schedule: CUs for projection + level chain; the reconstruction of the pass before takes the rest
     int fused;           // 1: one persistent kernel where the shape allows it, 0: always the three-kernel form
     int stagger;         // fused kernel: 1 = half first tile on odd workgroups
+    int lattice;         // 1: FSQ lattice codebooks take the lattice form of the level chain (the scan kernels stay behind it as the fallback)
     int lev2;            // level chain of one level group: 2 = lean form (fp32 values to the reconstruction) with 16 waves per workgroup
                          // (default), 1 = lean form with 8 waves, 0 = first form
 };
@@ -1265,6 +1301,7 @@ Tuning default_tuning()
     v.pipe_chunk = 0;       // off: measured slower (profiles/r02_pipeline_trace.txt): the kernels are bound per CU, not by HBM
     v.cap_ab = 160;
     v.lev2 = 2;
+    v.lattice = 1;          // FSQ lattice codebooks: the argmax without the scan (gram_wide.hpp, LAT), the scan kernels behind it as the fallback
     v.stagger = 0;
 #ifdef RQAE_GRAM_TOOLS
     static const Tuning env = [v]() mutable {
@@ -1274,6 +1311,7 @@ Tuning default_tuning()
         if (const char *e = getenv("RQAE_GRAM_PIPE")) { const long long c = atoll(e); v.pipe_chunk = c <= 0 ? 0 : ((c + 255) & ~255LL); }
         if (const char *e = getenv("RQAE_GRAM_CAP_AB")) { const int c = atoi(e); if (c >= 8) v.cap_ab = c; }
         if (const char *e = getenv("RQAE_GRAM_LEV2")) { const int a = atoi(e); v.lev2 = a < 0 || a > 2 ? 1 : a; }
+        if (const char *e = getenv("RQAE_GRAM_LATTICE")) v.lattice = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_STAGGER")) v.stagger = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_CTT")) v.c_tt = atoi(e) == 1 ? 1 : 2;
         return v;
@@ -1292,10 +1330,10 @@ int make_tuning(const rqae_hip_gram_options *o, Tuning &t)
     if (o->size != (int32_t)sizeof(rqae_hip_gram_options)) return gfail("gram options: size %d, this library expects %d", (int)o->size, (int)sizeof(rqae_hip_gram_options));
     if (o->fused >= 0) t.fused = o->fused != 0;
     if (o->pipe_chunk >= 0) t.pipe_chunk = o->pipe_chunk == 0 ? 0 : ((o->pipe_chunk + 255) & ~255LL);
-    if (o->proj > 3 || o->recon > 2 || o->lean_levels > 3) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
+    if (o->proj > 3 || o->recon > 2 || o->lean_levels > 4) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
     if (o->proj >= 1) t.proj = o->proj;
     if (o->recon >= 1) t.recon = o->recon;
-    if (o->lean_levels >= 0) t.lev2 = o->lean_levels;
+    if (o->lean_levels >= 0) { t.lev2 = o->lean_levels == 4 ? 2 : o->lean_levels; t.lattice = o->lean_levels == 4; }     // 0..3 name a scan kernel
     return 0;
 }
 
@@ -1448,7 +1486,22 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
     GHeader h;
     memset(&h, 0, sizeof(h));
     h.magic = GRAM_MAGIC; h.d = d; h.c = c; h.K = K; h.L = L; h.shared_cb = g.shared_cb;
+    // a lattice candidate: K = n^c for an n the threshold nibbles of lattice_best hold (c <= 13 < 16 in any case)
+    int nlat = 0;
+    if (g.shared_cb)
+        for (int n = 2; n <= 16 && !nlat; ++n) {
+            long long pw = 1;
+            for (int j = 0; j < c && pw <= K; ++j) pw *= n;
+            if (pw == K) nlat = n;
+        }
+    h.lattice_n = nlat;
     G_TRY(hipMemcpyAsync(b, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    if (nlat) {
+        hipLaunchKernelGGL(gram_pack_lattice_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, codebook, K, c, nlat, reinterpret_cast<GHeader *>(b));
+        G_TRY(hipGetLastError());
+        hipLaunchKernelGGL(gram_pack_lattice_verdict_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<GHeader *>(b));
+        G_TRY(hipGetLastError());
+    }
     G_TRY(hipMemsetAsync(b + lo.kconst, 0, sizeof(float) * (size_t)g.NOG * 16, s));
     hipLaunchKernelGGL(gram_pack_win_kernel, dim3(2048), dim3(256), 0, s, g, w_in, in_scale, reinterpret_cast<uint16_t *>(b + lo.win_img));
     G_TRY(hipGetLastError());
@@ -1658,12 +1711,40 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         }
         if (mark) G_TRY(hipEventRecord(ev[1], s));
         // ---- B
+        // FSQ lattice codebooks: the lattice form first (it returns at once unless the block's header names a lattice), the scan
+        // kernel of the shape behind it (it returns at once if the header does).  Both write the same outputs in the same formats:
+        // fp32 planes for the lean / wide reconstructions, operand rows otherwise.
+        const int *lat = tuning().lattice && g.shared_cb && (g.CP > 5 || (size_t)K * c * 4 <= 150 * 1024) ? reinterpret_cast<const int *>(static_cast<const char *>(packed) + offsetof(GHeader, lattice_n)) : nullptr;
+        if (lat) {
+            LevParams pl;
+            pl.P = P; pl.kconst = v.kconst; pl.gneg = v.gneg; pl.cb_img = v.cb_img; pl.cb_f32 = v.cb_f32; pl.cvimg = cvimg;
+            pl.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
+            pl.n_tokens = nt; pl.tok_pad = tp; pl.ntiles = (nt + 63) / 64;
+            pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c; pl.shared_cb = 1; pl.lat_flag = lat;
+            const int nw = 4;
+            long long nb = (pl.ntiles + nw - 1) / nw;
+            if (nb > 8LL * ncu) nb = 8LL * ncu;
+            const size_t lds = g.CP <= 5 ? (((size_t)K * c * 4 + 15) & ~(size_t)15) : 0;      // the fp32 rows (narrow codebooks)
+            auto go = [&](auto kern) -> int {
+                if (lds > 64 * 1024) G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nw * 64), lds, s, pl);
+                G_TRY(hipGetLastError());
+                return 0;
+            };
+            const bool multi = levels > g.GL;
+            int rc;
+            if (wide) rc = go(gram_levels_wide_kernel<13, 4, true, false, true>);
+            else if (lev2) rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 4, false, false, true>) : go(gram_levels_wide_kernel<5, 4, false, false, true>);
+            else if (multi) rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 4, true, true, true>) : go(gram_levels_wide_kernel<5, 4, true, true, true>);
+            else rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 4, false, true, true>) : go(gram_levels_wide_kernel<5, 4, false, true, true>);
+            if (rc) return rc;
+        }
         if (wide) {
             LevParams pb;
             pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
             pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
-            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
+            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat;
             // 4 waves per workgroup (one per SIMD) until the batch fills the chip twice over: 8 then halve the image's L2 -> LDS traffic
 #ifdef W_FORCE_NW8   /* tools build: two waves per SIMD on half the CUs */
             const int nw = 8;
@@ -1688,7 +1769,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
             pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
-            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
+            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat;
             const int nw = 8;
             const size_t lds = wide_levels_lds_bytes(g.NKC, nw);
             long long nb = (pb.ntiles + nw - 1) / nw;
@@ -1706,7 +1787,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pl.P = P; pl.kconst = v.kconst; pl.gneg = v.gneg; pl.cb_img = v.cb_img; pl.cb_f32 = v.cb_f32;
             pl.cvf = reinterpret_cast<float *>(cvimg); pl.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pl.n_tokens = nt; pl.tok_pad = tp; pl.ntiles = (nt + 63) / 64;
-            pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c;
+            pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c; pl.lat_flag = lat;
             pl.stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dump) + 32768 + (2048 + 8 * 36 * 4) * 8);
             // 16 waves per workgroup (four per SIMD: one wave's serial part behind the others' scans) where the tables leave room
             const int nw = (tuning().lev2 == 2 && c == g.CP && lev2_lds_bytes(c, K, 16) <= 160 * 1024) ? 16 : F_NW;
@@ -1729,7 +1810,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
         pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
         pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
-        pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb;
+        pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat;
         if (g.CP <= 5 && g.NKC == 1 && (!g.shared_cb || (!levels_resident_ok(g) && g.CP == 4 && c == 4 && tuning().lev2 == 3))) {
             // per-level codebooks (levels_free_ok): every level streams its own image through the ring.  Also a
             // variant (lean_levels = 3) for a narrow codebook too large for LDS (C5: K 4096, depth 32): gram_wide.hpp's streamed form

@@ -915,6 +915,7 @@ struct Lev2Params {
     long long *idx;            // [n_tokens][levels]
     long long n_tokens, tok_pad, ntiles;
     int levels, L, K, KTP, c;
+    const int *lat_flag;          // the block's lattice word (n >= 2: gram_wide.hpp's lattice form has run, this kernel returns), or NULL
     unsigned long long *stamps;   // tools build (-DRQAE_LEV_TIMELINE) only: 16 s_memtime / s_memrealtime stamps per wave
 };
 
@@ -936,6 +937,7 @@ __host__ __device__ inline size_t lev2_lds_bytes(int c, int K, int nw = F_NW)
 template <int CP, bool CEQ, int NW = F_NW>
 __global__ __launch_bounds__(NW * 64) void gram_levels2_kernel(Lev2Params p)
 {
+    if (p.lat_flag && *reinterpret_cast<const volatile int *>(p.lat_flag) >= 2) return;
     constexpr int GL = 8, GP = ((GL * CP + 15) / 16) * 16, NG = GP / 16, GB = (CP * CP + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;

@@ -16,6 +16,7 @@ __host__ __device__ inline size_t stream_lds_bytes(int nw) { return (size_t)SL_N
 template <int CP, bool MULTI, int NW>
 __global__ __launch_bounds__(NW * 64) void gram_levels_stream_kernel(LevParams p)
 {
+    if (p.lat_flag && *reinterpret_cast<const volatile int *>(p.lat_flag) >= 2) return;      // the lattice form ran (gram_wide.hpp)
     constexpr int GL = 8;
     constexpr int GP = ((GL * CP + 15) / 16) * 16;
     constexpr int GS = ((6 * CP * GL + 31) / 32) * 32;

@@ -55,6 +55,94 @@ __host__ __device__ constexpr int wide_piece_width(int d0, int d1, int d)
 
 __host__ __device__ inline size_t wide_levels_lds_bytes(int nkc, int nw) { return (size_t)W_NST * W_STT * nkc * 1024 + (size_t)nw * 4096; }   // nw = computing waves
 
+// ------------------------------------------------------------------------------------------------ FSQ lattice: the argmax without the scan
+// An FSQ codebook (rqae/model.py:63-72) is the lattice {linspace(-1, 1, n)}^c, row index = the digits of the coordinates (first
+// coordinate most significant), each row scaled to unit length ("round_fsq") or left as it is ("fsq").  For a projection q the row
+// that maximises q . row / |row| (and q . row) has, coordinate by coordinate, the sign of q and magnitudes in the order of |q|: the
+// larger |q_j|, the larger |row_j| (rearrangement inequality).  Such rows are given by how many coordinates reach each magnitude:
+// non-increasing thresholds c >= t_1 >= ... >= t_{nmag-1} >= 0 -- 6 candidates at n = 4, c = 5 (instead of 1024 rows), 15 at n = 5,
+// c = 4, 35 at n = 8, c = 4, ONE at n = 2.  Each candidate is scored exactly as the scan kernels' rescoring scores a row -- the
+// reference's q / ||q|| against the row as stored, fma chain in coordinate order, first maximum = lowest row among equal scores
+// (proportional lattice points of an odd n are bit-identical unit rows: the reference's argmax takes the first) -- so every token
+// whose top-1 / top-2 margin exceeds fp32 rounding gets the scan kernels' code.  A coordinate that is exactly zero ties between
+// its two signs: the negative digit is the lower row.  gram_pack_lattice_kernel (gram.hip) checks at pack time that the codebook
+// IS such a lattice and leaves n in the block's header; the kernels below run only then.
+typedef __attribute__((address_space(3))) const float lds_cf32;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+template <typename T> struct RowPtr;                              // rows in global memory (L2) or staged in LDS
+template <> struct RowPtr<const float *> {
+    static __device__ __forceinline__ f32x4 quad(const float *p, size_t i) { return *reinterpret_cast<const f32x4 *>(p + i); }
+};
+template <> struct RowPtr<lds_cf32 *> {
+    static __device__ __forceinline__ f32x4 quad(lds_cf32 *p, size_t i) { return *(lds_cf32x4 *)(p + i); }
+};
+
+template <int CP, typename PT>
+__device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, PT cbf)
+{
+    float xn[CP];
+    unit_dir<CP>(q, c, xn);
+    const int nth = (n + 1) / 2 - 1;                    // thresholds: magnitudes above the lowest one
+    const int base_pos = n / 2, base_neg = (n & 1) ? n / 2 : n / 2 - 1;
+    int rank[CP];
+#pragma unroll
+    for (int j = 0; j < CP; ++j) rank[j] = 0;
+    if (nth > 0) {
+        // rank_j = how many coordinates come before j in the order of descending |q| (equal magnitudes: lower coordinate first)
+#pragma unroll
+        for (int j = 0; j < CP; ++j)
+#pragma unroll
+            for (int i = 0; i < CP; ++i)
+                if (i != j) {
+                    const float ai = __builtin_fabsf(q[i]), aj = __builtin_fabsf(q[j]);
+                    const bool before = i < j ? ai >= aj : ai > aj;
+                    rank[j] += (i < c && before) ? 1 : 0;
+                }
+    }
+    int brow = 0;
+    float bsc = -INFINITY;
+    unsigned tp = 0u;                                   // nibble k: threshold t_{k+1}; wave-uniform (scalar registers)
+    for (;;) {
+        int row = 0;
+#pragma unroll
+        for (int j = 0; j < CP; ++j)
+            if (j < c) {
+                int mi = 0;
+                for (int k = 0; k < nth; ++k) mi += rank[j] < (int)((tp >> (4 * k)) & 15u) ? 1 : 0;
+                const int digit = q[j] > 0.0f ? base_pos + mi : base_neg - mi;
+                row = row * n + digit;
+            }
+        float sc = 0.0f;
+        if (c == CP && CP % 4 == 0) {
+#pragma unroll
+            for (int w = 0; w < CP / 4; ++w) {
+                const f32x4 v = RowPtr<PT>::quad(cbf, (size_t)row * CP + 4 * w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc = __builtin_fmaf(xn[4 * w + e], v[e], sc);
+            }
+        } else {
+            float f[CP];
+#pragma unroll
+            for (int j = 0; j < CP; ++j) f[j] = j < c ? cbf[(size_t)row * c + j] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < CP; ++j) sc = __builtin_fmaf(xn[j], f[j], sc);
+        }
+        const bool up = sc > bsc || (sc == bsc && row < brow);
+        bsc = up ? sc : bsc;
+        brow = up ? row : brow;
+        // next non-increasing threshold sequence
+        int k = nth - 1;
+        for (; k >= 0; --k) {
+            const unsigned tk = (tp >> (4 * k)) & 15u;
+            const unsigned lim = k == 0 ? (unsigned)c : (tp >> (4 * (k - 1))) & 15u;
+            if (tk < lim) { tp += 1u << (4 * k); break; }
+            tp &= ~(15u << (4 * k));
+        }
+        if (k < 0) break;
+    }
+    return brow;
+}
+
 // p.cvimg is used as float planes [levels][tok_pad][CVS] (or as operand rows: IMG below)
 // (second launch bound: a budget of 256 registers, so the MFMA accumulators stay in VGPRs.  With the 512 registers one wave per SIMD
 //  may take, hipcc parks them in AGPRs and pays four v_accvgpr_read + s_nop per accumulator before the maxima can read them.)
@@ -63,21 +151,43 @@ __host__ __device__ inline size_t wide_levels_lds_bytes(int nkc, int nw) { retur
 // pipe -- measured: 41.5 cycles per matrix instruction with the pieces issued by the computing waves, 16.3 with no refill at all.
 // MULTI: more than one level group (later groups' projections are corrected through the workspace).  NW = 4: one computing wave
 // per SIMD (C4 at its stated batch); NW = 8: two, so that one wave's serial part (rescoring, Gram updates) runs behind the other's scan.
-template <int CP, int NW, bool MULTI = true>
-__global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_levels_wide_kernel(LevParams p)
+// LAT: the lattice form -- no image, no scan, no loader waves, no LDS: lattice_best above picks the row; everything after it (the
+// straight-through values in the format the reconstruction reads, Gram updates, later groups' corrections, codes) is the same code.
+template <int CP, int NW, bool MULTI = true, bool IMG = (MULTI && CP <= 5), bool LAT = false>
+__global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 3 : 2)) void gram_levels_wide_kernel(LevParams p)
 {
+    // the lattice form runs when the block's header says the codebook is a lattice; the scan forms launched behind it then return
+    const int nlat = p.lat_flag ? *reinterpret_cast<const volatile int *>(p.lat_flag) : 0;
+    if (LAT ? nlat < 2 : nlat >= 2) return;
     using G = WideGeom<CP>;
     constexpr int GL = G::GL, GP = G::GP, NKC = G::NKC, GB = G::GB, STAGE = G::STAGE, CVS = G::CVS;
     static_assert(NKC == 1 || NKC == 3, "one or three k-steps per cosine contraction");
-    // IMG: the straight-through values leave as the bf16-piece operand rows gram_reconstruct_kernel reads (deep chains of a narrow
-    // codebook: C5), not as fp32 planes (gram_fused_kernel MODE 3 / gram_recon_wide_kernel)
-    constexpr bool IMG = MULTI && CP <= 5;
+    // IMG: the straight-through values leave as the bf16-piece operand rows gram_reconstruct_kernel / MODE 2 read (narrow codebooks
+    // outside the lean path), not as fp32 planes (gram_fused_kernel MODE 3 / gram_recon_wide_kernel)
+    static_assert(!IMG || CP <= 5, "operand rows are written for narrow codebooks only");
     static_assert((W_STT * NKC) % W_NWL == 0, "every loader wave issues the same number of pieces per stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
     const int c = p.c;
     char *xch = smem + W_NST * STAGE + wave * 4096;
     const float *cbf0 = p.cb_f32;                      // global (L2): [1 or L] x K x c fp32, + 64 zero rows at the end
+    // lattice form, narrow codebooks: the fp32 rows (K c 4 bytes: 20 KB at C2, 64 KB at C5) staged in LDS once per workgroup -- the
+    // candidates' rows are gathers one after the other, and from L2 each costs a round trip (measured: 9.5 k cycles per wave and level)
+    constexpr bool TAB = LAT && CP <= 5;
+    lds_cf32 *ltab = (lds_cf32 *)smem;
+    if constexpr (TAB) {
+        const int nfl = p.K * p.c;
+        __attribute__((address_space(3))) float *lw = (__attribute__((address_space(3))) float *)smem;
+        for (int i = threadIdx.x * 4; i < nfl; i += blockDim.x * 4) {
+            if (i + 4 <= nfl) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(cbf0 + i);
+                *(__attribute__((address_space(3))) f32x4 *)(lw + i) = v;
+            } else {
+                for (int e = 0; i + e < nfl; ++e) lw[i + e] = cbf0[i + e];
+            }
+        }
+        __syncthreads();
+    }
     float *cvf = reinterpret_cast<float *>(p.cvimg);
     const int nstage = (p.KTP + W_STT - 1) / W_STT;    // KTP is a multiple of 4; W_STT of 4 too: stages hold whole groups of 4 row tiles
     constexpr int PW = (W_STT * NKC) / W_NWL;          // pieces per loader wave and stage
@@ -100,7 +210,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
     unsigned a_brow = 0, a_scan = 0, a_hand = 0, a_resc = 0, a_gram = 0, a_multi = 0, a_load = 0;
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
-    if (wave >= NW) {
+    if (!LAT && wave >= NW) {
         // ---- loader waves: the barriers of the computing waves, stage for stage and level for level, and the image between them.
         // REGISTER-STAGED: plain global loads into registers, ds_write into the ring one stage ahead of the stage being multiplied
         // (tools build -DW_LOADER_DMA keeps the LDS-DMA form for comparison).  Stage k is loaded after barrier(k - 3), written into
@@ -197,7 +307,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
             }
             float cvh[MULTI ? GL : 1][CP];
             int codes[GL];
-            if constexpr (!MULTI) {
+            if constexpr (!MULTI && !IMG) {
                 // planes of the levels not run (max_layers < GL) are zeros for the reconstruction
                 if (live)
                     for (int lz = p.levels; lz < GL; ++lz) {
@@ -221,6 +331,12 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
 #pragma unroll
                     for (int j = 0; j < CP; ++j) n2 = __builtin_fmaf(q[j], q[j], n2);
                     const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
+                    int brow;
+                    if constexpr (LAT) {
+                        if constexpr (TAB) brow = lattice_best<CP>(q, c, nlat, ltab);
+                        else brow = lattice_best<CP>(q, c, nlat, cbf);
+                    } else {
+                    brow = [&]() __attribute__((always_inline)) -> int {
                     // ---- B operand rows of the wave's 64 tokens: 96 slots = 3 k-steps x 64 bytes per token, one k-step per trip
                     // through the exchange buffer (component j fills dwords 3j .. 3j+2: hi|mid, hi|lo, hi|mid)
                     u32x4 B[4][NKC];
@@ -398,7 +514,7 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
                     // maximum wins
                     float xn[CP];
                     unit_dir<CP>(q, c, xn);
-                    int brow = 64 * bgr + 4 * bg;
+                    int brow = 64 * bgr + 4 * bg;     // (shadows nothing: the caller takes the lambda's result)
                     float bsc = -INFINITY;
                     auto rescore4 = [&](int r0) {
                         float f[4 * CP];
@@ -435,15 +551,22 @@ __global__ __launch_bounds__((NW + W_NWL) * 64, NW == 8 ? 3 : 2) void gram_level
                             for (int r0 = 64 * bgr; r0 < 64 * bgr + 64; r0 += 4) rescore4(r0);
                         }
                     }
+                    W_T(t_e0);
+                    W_ACC(a_resc, t_d, t_e0);
+                    return brow;
+                    }();
+                    }
                     if (!okq) brow = 0;
                     codes[li] = brow;
                     W_T(t_e);
-                    W_ACC(a_resc, t_d, t_e);
+                    if constexpr (LAT) W_ACC(a_resc, t_a, t_e);
                     // ---- straight-through value (rqae/model.py:218-220), as fp32 for the reconstruction
                     float cvp[CP];
 #pragma unroll
                     for (int j = 0; j < CP; ++j) {
-                        const float cv = j < c ? cbf[(size_t)brow * c + j] : 0.0f;
+                        float cv;
+                        if constexpr (TAB) cv = j < c ? ltab[brow * c + j] : 0.0f;
+                        else cv = j < c ? cbf[(size_t)brow * c + j] : 0.0f;
                         const float df = cv - q[j];
                         cvp[j] = q[j] + df;
                         if constexpr (MULTI) cvh[li][j] = cvp[j];

@@ -500,7 +500,8 @@ def test_arm_auto_switches_on_batch_size():
         assert torch.equal(auto(large)[0], gram(large)[0])
 
 
-@pytest.mark.parametrize("variant", ["fused", "pipelined", "first kernels", "lean chain, 8 waves", "first level chain", "streamed level chain"])
+@pytest.mark.parametrize("variant", ["fused", "pipelined", "first kernels", "lean chain, 8 waves", "first level chain", "streamed level chain",
+                                     "scan, 16 waves"])
 def test_gram_kernel_variants(variant):
     """Every kernel selection of the arm (rqae_hip_gram_options, handed over per call) under the same Tier-2 bar, at a size that spans several
     tiles / passes and a ragged end; the defaults are what every other test in this file runs."""
@@ -513,7 +514,8 @@ def test_gram_kernel_variants(variant):
     m.gram_options = {"fused": _native.gram_options(fused=1), "pipelined": _native.gram_options(pipe_chunk=16384),
                       "first kernels": _native.gram_options(proj=2, recon=1), "lean chain, 8 waves": _native.gram_options(lean_levels=1),
                       "first level chain": _native.gram_options(lean_levels=0),
-                      "streamed level chain": _native.gram_options(lean_levels=3)}[variant]     # per call, no process-wide switch
+                      "streamed level chain": _native.gram_options(lean_levels=3),
+                      "scan, 16 waves": _native.gram_options(lean_levels=2)}[variant]     # per call, no process-wide switch
     for dt in (torch.bfloat16, torch.float16, torch.float32):
         q, idx, xs = run(m, x, dt)
         check_tier2(xs[sel], w, q[sel], idx[sel])

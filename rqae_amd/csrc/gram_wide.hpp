@@ -84,53 +84,82 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
     unit_dir<CP>(q, c, xn);
     const int nth = (n + 1) / 2 - 1;                    // thresholds: magnitudes above the lowest one
     const int base_pos = n / 2, base_neg = (n & 1) ? n / 2 : n / 2 - 1;
-    int rank[CP];
+    // the row with every coordinate at its lowest magnitude, and what one step up in magnitude of coordinate j adds to the row index
+    int row0 = 0, w[CP];
+    {
+        int pw = 1;
 #pragma unroll
-    for (int j = 0; j < CP; ++j) rank[j] = 0;
+        for (int j = CP - 1; j >= 0; --j) {
+            if (j < c) {
+                const bool pos = q[j] > 0.0f;
+                row0 += (pos ? base_pos : base_neg) * pw;
+                w[j] = pos ? pw : -pw;
+                pw *= n;
+            } else {
+                w[j] = 0;
+            }
+        }
+    }
+    // PW[t] = what raising the t coordinates of largest |q| by one magnitude adds (coordinates in descending |q|, equal ones by index)
+    int PW[CP + 1];
+    PW[0] = 0;
     if (nth > 0) {
-        // rank_j = how many coordinates come before j in the order of descending |q| (equal magnitudes: lower coordinate first)
+        int rank[CP];
 #pragma unroll
-        for (int j = 0; j < CP; ++j)
+        for (int jj = 0; jj < CP; ++jj) {
+            rank[jj] = 0;
 #pragma unroll
-            for (int i = 0; i < CP; ++i)
-                if (i != j) {
-                    const float ai = __builtin_fabsf(q[i]), aj = __builtin_fabsf(q[j]);
-                    const bool before = i < j ? ai >= aj : ai > aj;
-                    rank[j] += (i < c && before) ? 1 : 0;
+            for (int ii = 0; ii < CP; ++ii)
+                if (ii != jj) {
+                    const float ai = __builtin_fabsf(q[ii]), aj = __builtin_fabsf(q[jj]);
+                    const bool before = ii < jj ? ai >= aj : ai > aj;
+                    rank[jj] += (ii < c && before) ? 1 : 0;
                 }
+        }
+#pragma unroll
+        for (int r = 0; r < CP; ++r) {
+            int sw = 0;
+#pragma unroll
+            for (int jj = 0; jj < CP; ++jj) sw += rank[jj] == r ? w[jj] : 0;
+            PW[r + 1] = PW[r] + sw;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < CP; ++r) PW[r + 1] = 0;
     }
     int brow = 0;
     float bsc = -INFINITY;
-    unsigned tp = 0u;                                   // nibble k: threshold t_{k+1}; wave-uniform (scalar registers)
-    for (;;) {
-        int row = 0;
-#pragma unroll
-        for (int j = 0; j < CP; ++j)
-            if (j < c) {
-                int mi = 0;
-                for (int k = 0; k < nth; ++k) mi += rank[j] < (int)((tp >> (4 * k)) & 15u) ? 1 : 0;
-                const int digit = q[j] > 0.0f ? base_pos + mi : base_neg - mi;
-                row = row * n + digit;
-            }
+    auto score = [&](int row) __attribute__((always_inline)) {
         float sc = 0.0f;
         if (c == CP && CP % 4 == 0) {
 #pragma unroll
-            for (int w = 0; w < CP / 4; ++w) {
-                const f32x4 v = RowPtr<PT>::quad(cbf, (size_t)row * CP + 4 * w);
+            for (int w4 = 0; w4 < CP / 4; ++w4) {
+                const f32x4 v = RowPtr<PT>::quad(cbf, (size_t)row * CP + 4 * w4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sc = __builtin_fmaf(xn[4 * w + e], v[e], sc);
+                for (int e = 0; e < 4; ++e) sc = __builtin_fmaf(xn[4 * w4 + e], v[e], sc);
             }
         } else {
             float f[CP];
 #pragma unroll
-            for (int j = 0; j < CP; ++j) f[j] = j < c ? cbf[(size_t)row * c + j] : 0.0f;
+            for (int jj = 0; jj < CP; ++jj) f[jj] = jj < c ? cbf[row * c + jj] : 0.0f;
 #pragma unroll
-            for (int j = 0; j < CP; ++j) sc = __builtin_fmaf(xn[j], f[j], sc);
+            for (int jj = 0; jj < CP; ++jj) sc = __builtin_fmaf(xn[jj], f[jj], sc);
         }
         const bool up = sc > bsc || (sc == bsc && row < brow);
         bsc = up ? sc : bsc;
         brow = up ? row : brow;
-        // next non-increasing threshold sequence
+    };
+    // the candidates: thresholds c >= t_1 >= ... >= t_nth >= 0, row = row0 + sum_k PW[t_k]; an odometer of wave-uniform nibbles
+    // (scalar registers) walks them, PW is picked by compare-and-select so that it stays in registers
+    unsigned tp = 0u;                                   // nibble k: threshold t_{k+1}
+    for (;;) {
+        int row = row0;
+        for (int k = 0; k < nth; ++k) {
+            const int tk = (int)((tp >> (4 * k)) & 15u);
+#pragma unroll
+            for (int t = 1; t <= CP; ++t) row += tk == t ? PW[t] : 0;
+        }
+        score(row);
         int k = nth - 1;
         for (; k >= 0; --k) {
             const unsigned tk = (tp >> (4 * k)) & 15u;

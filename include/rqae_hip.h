@@ -208,6 +208,10 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
                        const float *codebook, const float *w_out, const float *b_out, int codebook_shared,
                        const float *in_scale /* [d] or NULL: a diagonal map in front of lin_in, folded into the W_in image */,
                        void *stream);
+/* n >= 2 when rqae_hip_gram_pack found the block's (shared) codebook to be the FSQ lattice {linspace(-1, 1, n)}^c of
+ * rqae/model.py:63-72 (rows of unit length, or plain), else 0; -1 if `packed` is no block.  Waits for `stream` -- the pack that
+ * wrote the answer; the only call of this arm that blocks.  A caller that got n >= 2 may pass lean_levels = 5 below. */
+int rqae_hip_gram_lattice(const void *packed, void *stream);
 size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels);
 /* Which kernels one rqae_hip_encode_gram call launches: per call, no process-wide state (NULL = the defaults, in
  * parentheses; a negative field keeps its default).  Every combination computes the same function under the same parity
@@ -219,7 +223,9 @@ size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_token
  *   lean_levels the level chain.  4 = for a codebook that rqae_hip_gram_pack found to be an FSQ lattice ({linspace(-1, 1, n)}^c,
  *               rows of unit length or plain: rqae/model.py:63-72) the lattice form -- the rows that can win follow from the
  *               signs and the order of |projection| (6 of 1024 at n = 4, c = 5), each scored like the scan's rescoring scores
- *               a row; no scan, no LDS -- and for any other codebook the scan kernel 2 names.  0..3 name a scan kernel and
+ *               a row; no scan -- and for any other codebook the scan kernel 2 names (launched behind the lattice form; on a
+ *               lattice it returns at once: 5 us).  5 = the lattice form alone, for a caller whom rqae_hip_gram_lattice has told
+ *               that the block holds a lattice (on any other block such a call computes nothing).  0..3 name a scan kernel and
  *               switch the lattice form off: 2 = (one level group, levels <= 8) fp32 straight-through values handed to the
  *               reconstruction kernel, 16 waves per workgroup, tables resident in LDS; 1 = the same with 8 waves;
  *               0 = the first form; 3 = the streamed form (codebook image through a 24 KB ring by loader waves)     (4)

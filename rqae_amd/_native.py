@@ -43,6 +43,7 @@ SYMBOLS = (
     "rqae_hip_gram_supported",
     "rqae_hip_gram_packed_bytes",
     "rqae_hip_gram_pack",
+    "rqae_hip_gram_lattice",
     "rqae_hip_gram_workspace_bytes",
     "rqae_hip_encode_gram",
     "rqae_hip_encode_gram_gemma_supported",
@@ -131,6 +132,8 @@ def lib():
     L.rqae_hip_gram_packed_bytes.restype = sz
     L.rqae_hip_gram_pack.argtypes = [vp, i, i, i, i, vp, vp, vp, vp, vp, i, vp, vp]
     L.rqae_hip_gram_pack.restype = i
+    L.rqae_hip_gram_lattice.argtypes = [vp, vp]
+    L.rqae_hip_gram_lattice.restype = i
     L.rqae_hip_gram_workspace_bytes.argtypes = [i, i, i, i, i64, i]
     L.rqae_hip_gram_workspace_bytes.restype = sz
     L.rqae_hip_encode_gram.argtypes = [vp, i, i, i, i, i, vp, i, i64, i, vp, vp, vp, ctypes.POINTER(GramOptions), vp]
@@ -266,7 +269,21 @@ def gram_pack(w_in, b_in, codebook, w_out, b_out, codebook_shared: bool, in_scal
                                       int(bool(codebook_shared)), in_scale.data_ptr() if in_scale is not None else None,
                                       _stream(w_in.device))
     _check(rc, "rqae_hip_gram_pack")
+    # an FSQ lattice?  Asked once, here (the one blocking call of the arm); the encode calls then launch the lattice form of the
+    # level chain without the scan kernel behind it (include/rqae_hip.h: lean_levels = 5)
+    with torch.cuda.device(w_in.device):
+        out.lattice_n = int(lib().rqae_hip_gram_lattice(out.data_ptr(), _stream(w_in.device)))
+    if out.lattice_n < 0:
+        _check(1, "rqae_hip_gram_lattice")
     return out
+
+
+def _gram_default_options(gpacked, options):
+    """No options from the caller: the defaults, with the scan kernel behind the lattice form left out when ``gram_pack`` has
+    learnt that the block holds a lattice."""
+    if options is None and getattr(gpacked, "lattice_n", 0) >= 2:
+        return gram_options(lean_levels=5)
+    return options
 
 
 def gram_workspace_bytes(dims, n_tokens: int, levels: int) -> int:
@@ -277,6 +294,7 @@ def gram_workspace_bytes(dims, n_tokens: int, levels: int) -> int:
 def encode_gram(gpacked, dims, codebook_shared: bool, x2d: torch.Tensor, levels: int, want_recon: bool = True,
                 workspace: torch.Tensor | None = None, options: GramOptions | None = None):
     """x2d [N,d] {f32,bf16,f16} -> (q_out [N,d] f32 | None, indices [N,levels] i64) on the matrix-core arm."""
+    options = _gram_default_options(gpacked, options)
     d, c, K, L_ = dims
     _require_cuda(x2d, "x")
     if x2d.dtype not in _X_DTYPES:
@@ -313,6 +331,7 @@ def encode_gram_gemma(gpacked_scaled, dims, hs: torch.Tensor, eps: float, levels
     _require_cuda(hs, "hidden states")
     if hs.dtype not in (torch.bfloat16, torch.float16) or not hs.is_contiguous() or hs.dim() != 3:
         raise RuntimeError("encode_gram_gemma: hidden states must be contiguous [B,S,d] bf16/f16")
+    options = _gram_default_options(gpacked_scaled, options)
     d, c, K, L_ = dims
     B, S, _ = hs.shape
     n = B * S
@@ -340,6 +359,7 @@ def encode_gram_gemma_patch(gpacked_scaled, dims, hs: torch.Tensor, inv_1pw: tor
     _require_cuda(hs, "hidden states")
     if hs.dtype not in (torch.bfloat16, torch.float16) or not hs.is_contiguous() or hs.dim() != 3:
         raise RuntimeError("encode_gram_gemma_patch: hidden states must be contiguous [B,S,d] bf16/f16")
+    options = _gram_default_options(gpacked_scaled, options)
     d, c, K, L_ = dims
     B, S, _ = hs.shape
     n = B * S
@@ -392,6 +412,7 @@ def decode_gram(gpacked, dims, codebook_shared: bool, idx2d: torch.Tensor) -> to
 
 def encode_gram_phases(gpacked, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True, options: GramOptions | None = None):
     """Measurement only: one encode_gram call timed per kernel -> [ms projection, ms level chain, ms reconstruction]."""
+    options = _gram_default_options(gpacked, options)
     d, c, K, L_ = dims
     n = x2d.shape[0]
     q = torch.empty((n, d), dtype=torch.float32, device=x2d.device) if want_recon else None

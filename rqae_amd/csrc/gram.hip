@@ -1330,10 +1330,12 @@ int make_tuning(const rqae_hip_gram_options *o, Tuning &t)
     if (o->size != (int32_t)sizeof(rqae_hip_gram_options)) return gfail("gram options: size %d, this library expects %d", (int)o->size, (int)sizeof(rqae_hip_gram_options));
     if (o->fused >= 0) t.fused = o->fused != 0;
     if (o->pipe_chunk >= 0) t.pipe_chunk = o->pipe_chunk == 0 ? 0 : ((o->pipe_chunk + 255) & ~255LL);
-    if (o->proj > 3 || o->recon > 2 || o->lean_levels > 4) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
+    if (o->proj > 3 || o->recon > 2 || o->lean_levels > 5) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
     if (o->proj >= 1) t.proj = o->proj;
     if (o->recon >= 1) t.recon = o->recon;
-    if (o->lean_levels >= 0) { t.lev2 = o->lean_levels == 4 ? 2 : o->lean_levels; t.lattice = o->lean_levels == 4; }     // 0..3 name a scan kernel
+    // 0..3 name a scan kernel; 4 = lattice form with the scan kernel behind it; 5 = lattice form alone (the caller has asked
+    // rqae_hip_gram_lattice about the block)
+    if (o->lean_levels >= 0) { t.lev2 = o->lean_levels >= 4 ? 2 : o->lean_levels; t.lattice = o->lean_levels >= 4 ? o->lean_levels - 3 : 0; }
     return 0;
 }
 
@@ -1517,6 +1519,21 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
                        reinterpret_cast<float *>(b + lo.bias_prefix));
     G_TRY(hipGetLastError());
     return 0;
+}
+
+// What rqae_hip_gram_pack found out about the block's codebook: n >= 2 when it is the FSQ lattice {linspace(-1, 1, n)}^c, else 0
+// (-1: not a block).  Waits for `stream` (the pack that wrote the header) -- the one call of this arm that does.
+int rqae_hip_gram_lattice(const void *packed, void *stream)
+{
+    if (!packed) { gfail("gram_lattice: null pointer"); return -1; }
+    GHeader h;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(&h, packed, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        gfail("gram_lattice: reading the header failed");
+        return -1;
+    }
+    if (h.magic != GRAM_MAGIC) { gfail("gram_lattice: not a block of rqae_hip_gram_pack"); return -1; }
+    return h.lattice_n >= 2 ? h.lattice_n : 0;
 }
 
 size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_tokens, int levels)
@@ -1724,7 +1741,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             const int nw = 4;
             long long nb = (pl.ntiles + nw - 1) / nw;
             if (nb > 8LL * ncu) nb = 8LL * ncu;
-            const size_t lds = g.CP <= 5 ? (((size_t)K * c * 4 + 15) & ~(size_t)15) : 0;      // the fp32 rows (narrow codebooks)
+            // narrow codebooks: the fp32 rows and the Gram blocks inside each level group, in LDS
+            const size_t lds = g.CP <= 5 ? (((size_t)K * c * 4 + 15) & ~(size_t)15) + (size_t)((levels + g.GL - 1) / g.GL) * g.GL * g.GL * g.GB * 4 : 0;
             auto go = [&](auto kern) -> int {
                 if (lds > 64 * 1024) G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nw * 64), lds, s, pl);
@@ -1738,6 +1756,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             else if (multi) rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 4, true, true, true>) : go(gram_levels_wide_kernel<5, 4, true, true, true>);
             else rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 4, false, true, true>) : go(gram_levels_wide_kernel<5, 4, false, true, true>);
             if (rc) return rc;
+            if (tuning().lattice == 2) return 0;          // the caller vouches for the block: no scan kernel behind the lattice form
         }
         if (wide) {
             LevParams pb;

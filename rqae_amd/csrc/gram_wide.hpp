@@ -100,29 +100,40 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
             }
         }
     }
-    // PW[t] = what raising the t coordinates of largest |q| by one magnitude adds (coordinates in descending |q|, equal ones by index)
+    // PW[t] = what raising the t coordinates of largest |q| by one magnitude adds: (|q_j|, step_j) sorted by descending |q_j| through a
+    // compare-exchange network (5 exchanges at 4 coordinates, 9 at 5), then prefix sums.  Coordinates of exactly equal magnitude
+    // may land either way round: the two rows then score the same in real arithmetic (a tie the reference decides by rounding)
     int PW[CP + 1];
     PW[0] = 0;
     if (nth > 0) {
-        int rank[CP];
+        float a[CP];
 #pragma unroll
-        for (int jj = 0; jj < CP; ++jj) {
-            rank[jj] = 0;
-#pragma unroll
-            for (int ii = 0; ii < CP; ++ii)
-                if (ii != jj) {
-                    const float ai = __builtin_fabsf(q[ii]), aj = __builtin_fabsf(q[jj]);
-                    const bool before = ii < jj ? ai >= aj : ai > aj;
-                    rank[jj] += (ii < c && before) ? 1 : 0;
-                }
+        for (int jj = 0; jj < CP; ++jj) a[jj] = jj < c ? __builtin_fabsf(q[jj]) : -1.0f;
+        auto cx = [&](auto i_c, auto j_c) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_c)::value, j2 = decltype(j_c)::value;
+            const bool sw = a[i] < a[j2];
+            const float ta = sw ? a[j2] : a[i], tb = sw ? a[i] : a[j2];
+            const int wa = sw ? w[j2] : w[i], wb = sw ? w[i] : w[j2];
+            a[i] = ta; a[j2] = tb; w[i] = wa; w[j2] = wb;
+        };
+#define CX(I, J) cx(std::integral_constant<int, I>{}, std::integral_constant<int, J>{})
+        if constexpr (CP == 4) {
+            CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3); CX(1, 2);
+        } else if constexpr (CP == 5) {
+            CX(0, 1); CX(3, 4); CX(2, 4); CX(2, 3); CX(0, 3); CX(0, 2); CX(1, 4); CX(1, 3); CX(1, 2);
+        } else {
+            // odd-even transposition: CP rounds (wide codebooks with more than two levels per coordinate: K = 3^6 .. 3^8, 4^6)
+            static_for<0, CP>([&](auto r_c) {
+                constexpr int r = decltype(r_c)::value;
+                static_for<0, (CP - (r & 1)) / 2>([&](auto k_c) {
+                    constexpr int i = 2 * decltype(k_c)::value + (r & 1);
+                    cx(std::integral_constant<int, i>{}, std::integral_constant<int, i + 1>{});
+                });
+            });
         }
+#undef CX
 #pragma unroll
-        for (int r = 0; r < CP; ++r) {
-            int sw = 0;
-#pragma unroll
-            for (int jj = 0; jj < CP; ++jj) sw += rank[jj] == r ? w[jj] : 0;
-            PW[r + 1] = PW[r] + sw;
-        }
+        for (int r = 0; r < CP; ++r) PW[r + 1] = PW[r] + w[r];
     } else {
 #pragma unroll
         for (int r = 0; r < CP; ++r) PW[r + 1] = 0;
@@ -215,8 +226,19 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
                 for (int e = 0; i + e < nfl; ++e) lw[i + e] = cbf0[i + e];
             }
         }
+        // ... and behind them the Gram blocks between levels of one level group ([group][li][li2][GB]: 7 KB at C2, 16 KB at C5)
+        __attribute__((address_space(3))) float *lg_w = lw + ((nfl + 3) & ~3);
+        const int ngr = ((p.levels + GL - 1) / GL) * GL * GL * (GB / 4);
+        for (int i = threadIdx.x; i < ngr; i += blockDim.x) {
+            const int wq4 = i % (GB / 4), li2 = (i / (GB / 4)) % GL, li1 = (i / (GB / 4) / GL) % GL, gr = i / (GB / 4) / GL / GL;
+            const int l1 = gr * GL + li1, l2 = gr * GL + li2;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (l1 < p.L && l2 < p.L) v = *reinterpret_cast<const f32x4 *>(p.gneg + ((size_t)l1 * p.L + l2) * GB + 4 * wq4);
+            *(__attribute__((address_space(3))) f32x4 *)(lg_w + 4 * i) = v;
+        }
         __syncthreads();
     }
+    lds_cf32 *lgram = ltab + ((p.K * p.c + 3) & ~3);
     float *cvf = reinterpret_cast<float *>(p.cvimg);
     const int nstage = (p.KTP + W_STT - 1) / W_STT;    // KTP is a multiple of 4; W_STT of 4 too: stages hold whole groups of 4 row tiles
     constexpr int PW = (W_STT * NKC) / W_NWL;          // pieces per loader wave and stage
@@ -672,7 +694,10 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
                                 f32x4 gv[8];
 #pragma unroll
                                 for (int w = 0; w < 8; ++w)
-                                    if (w0 + w < GB / 4) gv[w] = gb4[w0 + w];
+                                    if (w0 + w < GB / 4) {
+                                        if constexpr (TAB) gv[w] = *(lds_cf32x4 *)(lgram + ((lg * GL + li) * GL + li2) * GB + 4 * (w0 + w));      // broadcast read
+                                        else gv[w] = gb4[w0 + w];
+                                    }
 #pragma unroll
                                 for (int w = 0; w < 8; ++w)
 #pragma unroll

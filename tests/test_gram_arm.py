@@ -268,6 +268,51 @@ def test_gram_c5_streamed_codebook_depth_32():
     print(f"gram arm, C5 depth 32, {n} tokens: {len(rows)} low-margin tokens differ from the exact arm, all adjudicated")
 
 
+def test_lattice_form_and_its_fallback():
+    """rqae_hip_gram_pack checks whether the shared codebook is an FSQ lattice (include/rqae_hip.h: rqae_hip_gram_lattice).  On a
+    lattice the level chain takes the lattice form (candidates from signs and the order of |projection|, csrc/gram_wide.hpp); on
+    anything else -- here the same lattice with one row moved by 1e-3 -- the scan kernels run.  Both under the Tier-2 bar; lean_levels
+    = 4 (lattice form, scan kernel behind it) and the module's default (5 when the block is known to be a lattice) give the same codes."""
+    expect_n = {"C1": 4, "C2": 4, "P": 5, "C4": 2, "C5": 8}
+    for name, n_lat in expect_n.items():
+        cfg = synth.CONFIGS[name]
+        w = synth.weights(3, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+        m = make_model(cfg, w, "gram")
+        assert m.gram_packed_weights().lattice_n == n_lat, name
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(3, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    x = synth.activations(17, 3000, cfg["dim"])
+    m = make_model(cfg, w, "gram")
+    q5, i5, xs = run(m, x, torch.float32)                         # default: lattice form alone
+    check_tier2(xs, w, q5, i5)
+    m.gram_options = _native.gram_options(lean_levels=4)          # lattice form, the scan kernel launched behind it (it returns at once)
+    q4, i4, _ = run(m, x, torch.float32)
+    assert np.array_equal(i4, i5) and np.array_equal(q4, q5)
+    m.gram_options = _native.gram_options(lean_levels=2)          # the scan kernel
+    q2, i2, _ = run(m, x, torch.float32)
+    check_tier2(xs, w, q2, i2)
+    assert (i2 != i5).any(axis=1).sum() <= 2                      # the two forms part only on near-ties
+    # not a lattice: one row moved
+    w2 = dict(w, codebook=w["codebook"].copy())
+    w2["codebook"][:, 77, 2] += 1e-3
+    m2 = make_model(cfg, w2, "gram")
+    assert m2.gram_packed_weights().lattice_n == 0
+    for opts in (None, _native.gram_options(lean_levels=4)):
+        m2.gram_options = opts
+        q, idx, xs2 = run(m2, x, torch.float32)
+        check_tier2(xs2, w2, q, idx)
+    # the plain (not unit-length) lattice of quantization_method "fsq" is a lattice too
+    cfg_f = dict(cfg, quantization_method="fsq")
+    mf = RQAE(**cfg_f, arm="gram").eval()
+    sd = synth.state_dict_from_weights(w)
+    sd["codebook"] = mf.codebook.detach().clone()
+    mf.load_state_dict(sd)
+    mf = mf.to(DEV)
+    assert mf.gram_packed_weights().lattice_n == 4
+    q, idx, xs3 = run(mf, x, torch.float32)
+    check_tier2(xs3, dict(w, codebook=mf.codebook.detach().cpu().numpy()), q, idx)
+
+
 @pytest.mark.parametrize("shape", [dict(dim=512, codebook_dim=5, codebook_size=1024, num_quantizers=8),
                                    dict(dim=2304, codebook_dim=4, codebook_size=2048, num_quantizers=19),
                                    dict(dim=512, codebook_dim=5, codebook_size=592, num_quantizers=11),

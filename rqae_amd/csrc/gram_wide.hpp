@@ -149,14 +149,21 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sc = __builtin_fmaf(xn[4 * w4 + e], v[e], sc);
             }
+        } else if (c == CP) {
+            float f[CP];
+#pragma unroll
+            for (int jj = 0; jj < CP; ++jj) f[jj] = cbf[row * CP + jj];
+#pragma unroll
+            for (int jj = 0; jj < CP; ++jj) sc = __builtin_fmaf(xn[jj], f[jj], sc);
         } else {
             float f[CP];
 #pragma unroll
-            for (int jj = 0; jj < CP; ++jj) f[jj] = jj < c ? cbf[row * c + jj] : 0.0f;
+            for (int jj = 0; jj < CP; ++jj) f[jj] = cbf[row * c + (jj < c ? jj : 0)];
 #pragma unroll
-            for (int jj = 0; jj < CP; ++jj) sc = __builtin_fmaf(xn[jj], f[jj], sc);
+            for (int jj = 0; jj < CP; ++jj) sc = __builtin_fmaf(xn[jj], jj < c ? f[jj] : 0.0f, sc);
         }
-        const bool up = sc > bsc || (sc == bsc && row < brow);
+        // (bitwise, not short-circuit: hipcc turns `a > b || (a == b && r < s)` into exec-masked branches)
+        const bool up = (sc > bsc) | ((sc == bsc) & (row < brow));
         bsc = up ? sc : bsc;
         brow = up ? row : brow;
     };
@@ -197,7 +204,9 @@ template <int CP, int NW, bool MULTI = true, bool IMG = (MULTI && CP <= 5), bool
 __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 3 : 2)) void gram_levels_wide_kernel(LevParams p)
 {
     // the lattice form runs when the block's header says the codebook is a lattice; the scan forms launched behind it then return
-    const int nlat = p.lat_flag ? *reinterpret_cast<const volatile int *>(p.lat_flag) : 0;
+    // (readfirstlane: the word is the same for every lane, and the odometer of lattice_best must stay in scalar registers -- as a
+    //  per-lane value hipcc turns its loops into exec-masked ones)
+    const int nlat = p.lat_flag ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int *>(p.lat_flag)) : 0;
     if (LAT ? nlat < 2 : nlat >= 2) return;
     using G = WideGeom<CP>;
     constexpr int GL = G::GL, GP = G::GP, NKC = G::NKC, GB = G::GB, STAGE = G::STAGE, CVS = G::CVS;

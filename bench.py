@@ -184,6 +184,7 @@ def main():
                     help="gram = matrix-core arm (Tier-2 parity, the fast path); exact = canonical fp32 order (bit-exact)")
     ap.add_argument("--codes-only", action="store_true", help="time RQAE.encode (no reconstruction written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup-burst", type=int, default=8, help="steps enqueued between two synchronisations of the spin-up")
     ap.add_argument("--spinup-ms", type=float, default=300.0,
                     help="untimed run of the same step before the warm-up steps (disclosed as spinup_ms in the line); 0 = none")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the 524288- and 1048576-token legs")
@@ -266,10 +267,10 @@ def main():
             if spinup_ms > 0:
                 t0 = time.perf_counter()
                 while (time.perf_counter() - t0) * 1e3 < spinup_ms:
-                    for _ in range(8):
+                    for _ in range(args.spinup_burst):
                         fn(x)
                     torch.cuda.synchronize()
-                    spin_steps += 8
+                    spin_steps += args.spinup_burst
                 spin_s = time.perf_counter() - t0
             elapsed = sharding.timed_steps(step, steps, warmup, barrier)
         ev_ms = [a.elapsed_time(b) for a, b in evs[warmup:]]

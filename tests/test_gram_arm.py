@@ -313,6 +313,31 @@ def test_lattice_form_and_its_fallback():
     check_tier2(xs3, dict(w, codebook=mf.codebook.detach().cpu().numpy()), q, idx)
 
 
+@pytest.mark.parametrize("name", ["C2", "P"])
+def test_lattice_form_exact_ties_take_the_reference_row(name):
+    """A projection coordinate that is exactly zero ties between the rows that differ in that coordinate's sign (and, for an odd
+    n, proportional lattice points are the same unit row): the reference's argmax takes the FIRST maximum.  With lin_in rows and
+    biases zeroed at some levels every token has such ties there; the lattice form must give the exact arm's codes (the exact arm
+    is bit-equal to the oracle), up to the usual handful of low-margin tokens."""
+    cfg = dict(synth.CONFIGS[name])
+    cfg["num_quantizers"] = min(cfg["num_quantizers"], 8)
+    w = synth.weights(29, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    w = {k: v.copy() for k, v in w.items()}
+    for l, j in ((0, 1), (2, 0), (2, 3), (5, cfg["codebook_dim"] - 1)):
+        w["w_in"][l, j, :] = 0.0
+        w["b_in"][l, j] = 0.0
+    mg_, me_ = make_model(cfg, w, "gram"), make_model(cfg, w, "exact")
+    assert mg_.gram_packed_weights().lattice_n >= 2
+    n = 6000
+    x = synth.activations(77, n, cfg["dim"])
+    x[:7] = 0.0                                                   # and a few all-zero tokens: the projection is the bias chain alone
+    qg, ig, xs = run(mg_, x, torch.float32)
+    qe, ie, _ = run(me_, x, torch.float32)
+    differ = (ig != ie).any(axis=1)
+    assert differ.sum() <= 3, f"{differ.sum()} tokens differ from the exact arm"
+    check_tier2(xs, w, qg, ig)
+
+
 @pytest.mark.parametrize("shape", [dict(dim=512, codebook_dim=5, codebook_size=1024, num_quantizers=8),
                                    dict(dim=2304, codebook_dim=4, codebook_size=2048, num_quantizers=19),
                                    dict(dim=512, codebook_dim=5, codebook_size=592, num_quantizers=11),

@@ -1751,10 +1751,13 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             };
             const bool multi = levels > g.GL;
             int rc;
-            if (wide) rc = go(gram_levels_wide_kernel<13, 4, true, false, true>);
-            else if (lev2) rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 4, false, false, true>) : go(gram_levels_wide_kernel<5, 4, false, false, true>);
-            else if (multi) rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 4, true, true, true>) : go(gram_levels_wide_kernel<5, 4, true, true, true>);
-            else rc = g.CP == 4 ? go(gram_levels_wide_kernel<4, 4, false, true, true>) : go(gram_levels_wide_kernel<5, 4, false, true, true>);
+            const bool ceq = c == g.CP;       // no padded coordinate: the common case, with c a compile-time fact
+#define LATK(CPV, MV, IV) (ceq ? go(gram_levels_wide_kernel<CPV, 4, MV, IV, true, true>) : go(gram_levels_wide_kernel<CPV, 4, MV, IV, true, false>))
+            if (wide) rc = ceq ? go(gram_levels_wide_kernel<13, 4, true, false, true, true>) : go(gram_levels_wide_kernel<13, 4, true, false, true, false>);
+            else if (lev2) rc = g.CP == 4 ? LATK(4, false, false) : LATK(5, false, false);
+            else if (multi) rc = g.CP == 4 ? LATK(4, true, true) : LATK(5, true, true);
+            else rc = g.CP == 4 ? LATK(4, false, true) : LATK(5, false, true);
+#undef LATK
             if (rc) return rc;
             if (tuning().lattice == 2) return 0;          // the caller vouches for the block: no scan kernel behind the lattice form
         }

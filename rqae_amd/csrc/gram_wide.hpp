@@ -169,6 +169,14 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
     };
     // the candidates: thresholds c >= t_1 >= ... >= t_nth >= 0, row = row0 + sum_k PW[t_k]; an odometer of wave-uniform nibbles
     // (scalar registers) walks them, PW is picked by compare-and-select so that it stays in registers
+    if (nth == 1) {
+        // two magnitudes (n = 3, 4: C1, C2): the c + 1 candidates unrolled, PW indexed at compile time
+        static_for<0, CP + 1>([&](auto t_c) {
+            constexpr int t1 = decltype(t_c)::value;
+            if (t1 <= c) score(row0 + PW[t1]);
+        });
+        return brow;
+    }
     unsigned tp = 0u;                                   // nibble k: threshold t_{k+1}
     for (;;) {
         int row = row0;
@@ -200,7 +208,8 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
 // per SIMD (C4 at its stated batch); NW = 8: two, so that one wave's serial part (rescoring, Gram updates) runs behind the other's scan.
 // LAT: the lattice form -- no image, no scan, no loader waves, no LDS: lattice_best above picks the row; everything after it (the
 // straight-through values in the format the reconstruction reads, Gram updates, later groups' corrections, codes) is the same code.
-template <int CP, int NW, bool MULTI = true, bool IMG = (MULTI && CP <= 5), bool LAT = false>
+// CEQ: c == CP as a compile-time fact (no padded coordinate: the selects that mask one disappear).
+template <int CP, int NW, bool MULTI = true, bool IMG = (MULTI && CP <= 5), bool LAT = false, bool CEQ = false>
 __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 3 : 2)) void gram_levels_wide_kernel(LevParams p)
 {
     // the lattice form runs when the block's header says the codebook is a lattice; the scan forms launched behind it then return
@@ -217,7 +226,7 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
     static_assert((W_STT * NKC) % W_NWL == 0, "every loader wave issues the same number of pieces per stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, n = lane & 15;
-    const int c = p.c;
+    const int c = CEQ ? CP : p.c;
     char *xch = smem + W_NST * STAGE + wave * 4096;
     const float *cbf0 = p.cb_f32;                      // global (L2): [1 or L] x K x c fp32, + 64 zero rows at the end
     // lattice form, narrow codebooks: the fp32 rows (K c 4 bytes: 20 KB at C2, 64 KB at C5) staged in LDS once per workgroup -- the

@@ -372,6 +372,32 @@ def test_gram_per_level_codebooks(shape):
     check_tier2(xs, dict(w, codebook=m._codebook_used.cpu().numpy()), q3, i3, levels=lv)
 
 
+@pytest.mark.parametrize("cd,cs,levels,n", [(7, 3, 6, 900),       # K 2187 = 3^7: two magnitudes, 13-wide sorting network, c < the padded width
+                                            (6, 4, 9, 700),       # K 4096 = 4^6: three level groups of four
+                                            (8, 2, 5, 600),       # K 256 = 2^8: the row is the sign pattern
+                                            (9, 2, 16, 400)])     # K 512, depth 16
+def test_gram_wide_shared_lattices_between_c6_and_c12(cd, cs, levels, n):
+    """6 <= c <= 12 rides in the 13-wide kernels (csrc/gram_wide.hpp) with padded coordinates; as FSQ lattices these shapes take the
+    lattice form (odd-even transposition network for the order of |projection|, c a run-time value), and with lean_levels = 2 the
+    scan kernels: both under the Tier-2 bar, and the same codes but for near-ties."""
+    cfg = dict(dim=512, codebook_dim=cd, codebook_size=cs, num_quantizers=levels)
+    w = synth.weights(63, cfg["dim"], cd, levels, cs)
+    m = make_model(cfg, w, "gram")
+    assert m.gram_packed_weights().lattice_n == cs
+    x = synth.activations(50 + cd, n, cfg["dim"])
+    q, idx, xs = run(m, x, torch.float32)
+    assert idx.max() < cs ** cd
+    check_tier2(xs, w, q, idx)
+    qb, ib, xb = run(m, x, torch.bfloat16)
+    check_tier2(xb, w, qb, ib)
+    m.gram_options = _native.gram_options(lean_levels=2)
+    q2, i2, _ = run(m, x, torch.float32)
+    check_tier2(xs, w, q2, i2)
+    assert (i2 != idx).any(axis=1).sum() <= max(2, n // 200)
+    q3, i3, xs3 = run(m, x[:300], torch.float32, max_layers=max(1, levels // 2))
+    check_tier2(xs3, w, q3, i3, levels=max(1, levels // 2))
+
+
 def test_gram_c4_wide_codebook_depth_16():
     """BASELINE configs[3] as stated: d 3584, c 13, K 8192 = 2^13, depth 16 on the matrix cores (csrc/gram_wide.hpp: three k-steps
     per cosine contraction, the 1.5 MB codebook image streamed through LDS, four level groups of four levels, reconstruction with

@@ -169,24 +169,34 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
     };
     // the candidates: thresholds c >= t_1 >= ... >= t_nth >= 0, row = row0 + sum_k PW[t_k]; an odometer of wave-uniform nibbles
     // (scalar registers) walks them, PW is picked by compare-and-select so that it stays in registers
-    if (nth == 1) {
-        // two magnitudes (n = 3, 4: C1, C2): the c + 1 candidates unrolled, PW indexed at compile time
+    if (nth <= 1) {
+        // one magnitude (n = 2: C4 -- the row is the sign pattern) or two (n = 3, 4: C1, C2 -- c + 1 candidates, unrolled, PW
+        // indexed at compile time)
+        const int tmax = nth ? c : 0;
         static_for<0, CP + 1>([&](auto t_c) {
             constexpr int t1 = decltype(t_c)::value;
-            if (t1 <= c) score(row0 + PW[t1]);
+            if (t1 <= tmax) score(row0 + PW[t1]);
         });
         return brow;
     }
+    // three and more magnitudes (n >= 5: the pretrained shape, C5): the odometer walks the first nth - 1 thresholds, the last one
+    // (0 .. its predecessor) is unrolled with PW indexed at compile time -- 12 vector instructions per candidate instead of 30
+    const int no = nth - 1;                             // thresholds in the odometer
     unsigned tp = 0u;                                   // nibble k: threshold t_{k+1}
     for (;;) {
-        int row = row0;
-        for (int k = 0; k < nth; ++k) {
+        int rowb = row0;
+        int tlast = c;                                  // the predecessor of the unrolled threshold
+        for (int k = 0; k < no; ++k) {
             const int tk = (int)((tp >> (4 * k)) & 15u);
 #pragma unroll
-            for (int t = 1; t <= CP; ++t) row += tk == t ? PW[t] : 0;
+            for (int t = 1; t <= CP; ++t) rowb += tk == t ? PW[t] : 0;
+            tlast = tk;
         }
-        score(row);
-        int k = nth - 1;
+        static_for<0, CP + 1>([&](auto t_c) {
+            constexpr int tl = decltype(t_c)::value;
+            if (tl <= tlast) score(rowb + PW[tl]);
+        });
+        int k = no - 1;
         for (; k >= 0; --k) {
             const unsigned tk = (tp >> (4 * k)) & 15u;
             const unsigned lim = k == 0 ? (unsigned)c : (tp >> (4 * (k - 1))) & 15u;

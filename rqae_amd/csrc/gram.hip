@@ -1738,11 +1738,13 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pl.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pl.n_tokens = nt; pl.tok_pad = tp; pl.ntiles = (nt + 63) / 64;
             pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c; pl.shared_cb = 1; pl.lat_flag = lat;
-            const int nw = 4;
+            // narrow codebooks: 4 waves per workgroup, the fp32 rows and the Gram blocks inside each level group in LDS; wide ones: 8
+            // waves, persistent, the whole upper triangle of Gram blocks in LDS (82 KB at depth 16: one workgroup per CU)
+            const int nw = wide ? 8 : 4;
             long long nb = (pl.ntiles + nw - 1) / nw;
-            if (nb > 8LL * ncu) nb = 8LL * ncu;
-            // narrow codebooks: the fp32 rows and the Gram blocks inside each level group, in LDS
-            const size_t lds = g.CP <= 5 ? (((size_t)K * c * 4 + 15) & ~(size_t)15) + (size_t)((levels + g.GL - 1) / g.GL) * g.GL * g.GL * g.GB * 4 : 0;
+            if (nb > (wide ? 1LL : 8LL) * ncu) nb = (wide ? 1LL : 8LL) * ncu;
+            const size_t lds = g.CP <= 5 ? (((size_t)K * c * 4 + 15) & ~(size_t)15) + (size_t)((levels + g.GL - 1) / g.GL) * g.GL * g.GL * g.GB * 4
+                                         : (size_t)L * (L - 1) / 2 * g.GB * 4;
             auto go = [&](auto kern) -> int {
                 if (lds > 64 * 1024) G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nw * 64), lds, s, pl);
@@ -1753,7 +1755,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             int rc;
             const bool ceq = c == g.CP;       // no padded coordinate: the common case, with c a compile-time fact
 #define LATK(CPV, MV, IV) (ceq ? go(gram_levels_wide_kernel<CPV, 4, MV, IV, true, true>) : go(gram_levels_wide_kernel<CPV, 4, MV, IV, true, false>))
-            if (wide) rc = ceq ? go(gram_levels_wide_kernel<13, 4, true, false, true, true>) : go(gram_levels_wide_kernel<13, 4, true, false, true, false>);
+            if (wide) rc = ceq ? go(gram_levels_wide_kernel<13, 8, true, false, true, true>) : go(gram_levels_wide_kernel<13, 8, true, false, true, false>);
             else if (lev2) rc = g.CP == 4 ? LATK(4, false, false) : LATK(5, false, false);
             else if (multi) rc = g.CP == 4 ? LATK(4, true, true) : LATK(5, true, true);
             else rc = g.CP == 4 ? LATK(4, false, true) : LATK(5, false, true);

@@ -267,6 +267,26 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
         __syncthreads();
     }
     lds_cf32 *lgram = ltab + ((p.K * p.c + 3) & ~3);
+    // lattice form, wide codebooks (C4): every Gram block a chain can need -- level l onto a later level l2, the upper triangle of
+    // [L][L], 120 blocks of 172 floats = 82 KB at depth 16 -- staged in LDS once per workgroup.  Read from L2 by every wave for
+    // itself (43 dwordx4 loads of one address per block, ~100 blocks per wave and level group) they bound the kernel on the
+    // vector-memory pipe: 1.06 ms per 262 144 tokens.
+    constexpr bool TABW = LAT && CP > 5;
+    lds_cf32 *lgw = (lds_cf32 *)smem;
+    auto tri = [&](int l1, int l2) { return l1 * p.L - l1 * (l1 + 1) / 2 + (l2 - l1 - 1); };      // block (l1 < l2) of the triangle
+    if constexpr (TABW) {
+        __attribute__((address_space(3))) float *gw = (__attribute__((address_space(3))) float *)smem;
+        const int nblk = p.L * (p.L - 1) / 2;
+        for (int i = threadIdx.x; i < nblk * (GB / 4); i += blockDim.x) {
+            const int b = i / (GB / 4), w4 = i % (GB / 4);
+            int l1 = 0, rem = b;                          // b -> (l1, l2): rows of the triangle have L - 1 - l1 blocks
+            while (rem >= p.L - 1 - l1) { rem -= p.L - 1 - l1; ++l1; }
+            const int l2 = l1 + 1 + rem;
+            *(__attribute__((address_space(3))) f32x4 *)(gw + (size_t)b * GB + 4 * w4) =
+                *reinterpret_cast<const f32x4 *>(p.gneg + ((size_t)l1 * p.L + l2) * GB + 4 * w4);
+        }
+        __syncthreads();
+    }
     float *cvf = reinterpret_cast<float *>(p.cvimg);
     const int nstage = (p.KTP + W_STT - 1) / W_STT;    // KTP is a multiple of 4; W_STT of 4 too: stages hold whole groups of 4 row tiles
     constexpr int PW = (W_STT * NKC) / W_NWL;          // pieces per loader wave and stage
@@ -724,6 +744,7 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
                                 for (int w = 0; w < 8; ++w)
                                     if (w0 + w < GB / 4) {
                                         if constexpr (TAB) gv[w] = *(lds_cf32x4 *)(lgram + ((lg * GL + li) * GL + li2) * GB + 4 * (w0 + w));      // broadcast read
+                                        else if constexpr (TABW) gv[w] = *(lds_cf32x4 *)(lgw + tri(l, l2) * GB + 4 * (w0 + w));
                                         else gv[w] = gb4[w0 + w];
                                     }
 #pragma unroll
@@ -771,7 +792,10 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
                             f32x4 gv[HB];
 #pragma unroll
                             for (int w = 0; w < HB; ++w)
-                                if (w0 + w < GB / 4) gv[w] = gb4[w0 + w];
+                                if (w0 + w < GB / 4) {
+                                    if constexpr (TABW) gv[w] = *(lds_cf32x4 *)(lgw + tri(lg * GL + li, l2) * GB + 4 * (w0 + w));
+                                    else gv[w] = gb4[w0 + w];
+                                }
 #pragma unroll
                             for (int w = 0; w < HB; ++w)
 #pragma unroll

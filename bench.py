@@ -117,7 +117,7 @@ def cpu_baseline(w, target_seconds=12.0):
                       "(BASELINE.md section 2: 4.3 k tok/s on 8 threads)"}
 
 
-def parity_check(np, torch, model, x, w, gram, codes_only, n_check=4096):
+def parity_check(np, torch, model, x, w, gram, codes_only, n_check=65536):
     """After the timed region: the first `n_check` tokens of the timed batch through the product path once more and through the
     CPU oracle (the checker, never the thing measured).  Exact arm: every code must equal the oracle's.  Matrix-core arm:
     SURVEY 8(c) Tier 2 -- codes equal wherever the oracle's top-1/top-2 margin is >= 1e-5; tokens that differ are counted
@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=300.0,
                     help="untimed run of the same step before the warm-up steps (disclosed as spinup_ms in the line); 0 = none")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the 524288- and 1048576-token legs")
-    ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle check of a 4096-token slice")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle check of a 65536-token slice of the timed batch")
     ap.add_argument("--stub", action="store_true", help="CPU/gloo rehearsal of the multi-rank orchestration (tests only)")
     args = ap.parse_args()
 
@@ -386,9 +386,11 @@ def main():
                        "sharding": f"token-sharded x{world}, weights replicated, no collective",
                        "world_size_seen": dist.get_world_size() if dist is not None else 1,
                        "per_rank_seconds": per_rank,
-                       "arm": ("gram: all-levels projection + c-space level chain + reconstruction on v_mfma_f32_16x16x32_bf16, "
-                               "fp32 operands as 3 exact bf16 pieces, fp32 accumulate (Tier-2 parity: codes equal wherever the "
-                               "top-1/top-2 margin >= 1e-5, reconstruction <= 1e-5 rel)") if gram
+                       "arm": ("gram: all-levels projection and reconstruction on v_mfma_f32_16x16x32_bf16 (fp32 operands as 3 exact "
+                               "bf16 pieces, fp32 accumulate), c-space level chain between them -- for this FSQ lattice codebook the "
+                               "candidate rows from the signs and the order of the projection, scored in the reference's fp32 order, "
+                               "no codebook scan (Tier-2 parity: codes equal wherever the top-1/top-2 margin >= 1e-5, "
+                               "reconstruction <= 1e-5 rel)") if gram
                        else "exact: canonical fp32 order, bit-equal to the CPU oracle; " + _native.kernel_info(D, C, K, L)},
             "roofline": roof,
         }

@@ -4,7 +4,8 @@
  * inputs, runs this program and compares its outputs with the oracle.
  *
  *   host_smoke <dir>     reads <dir>/meta.txt  (d c K L n levels), w_in.bin b_in.bin cb.bin w_out.bin b_out.bin x.bin
- *                        writes <dir>/idx.bin (int64), q.bin (fp32), dec.bin (fp32)
+ *                        writes <dir>/idx.bin (int64), q.bin (fp32), dec.bin (fp32) -- the exact arm -- and idx_gram.bin, q_gram.bin,
+ *                        lattice.txt -- the matrix-core arm with its per-call options struct and the lattice query
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -90,6 +91,40 @@ int main(int argc, char **argv)
 
     if (dump(dir, "idx.bin", idx, (size_t)n * levels * sizeof(int64_t)) || dump(dir, "q.bin", q, (size_t)n * d * f) ||
         dump(dir, "dec.bin", dec, (size_t)n * d * f)) { fprintf(stderr, "cannot write outputs\n"); return 7; }
+
+    /* the matrix-core arm: its own block, what the pack found out about the codebook, options per call */
+    if (rqae_hip_gram_supported(d, c, K, L, 1)) {
+        const size_t gbytes = rqae_hip_gram_packed_bytes(d, c, K, L, 1), wbytes = rqae_hip_gram_workspace_bytes(d, c, K, L, n, levels);
+        if (!gbytes || !wbytes) { fprintf(stderr, "gram sizes: %s\n", rqae_hip_last_error()); return 3; }
+        void *gpacked = NULL, *ws = NULL;
+        CHECK_HIP(hipMalloc(&gpacked, gbytes));
+        CHECK_HIP(hipMalloc(&ws, wbytes));
+        CHECK_RQAE(rqae_hip_gram_pack(gpacked, d, c, K, L, w_in, b_in, cb, w_out, b_out, 1, NULL, stream));
+        const int lattice_n = rqae_hip_gram_lattice(gpacked, stream);       /* waits for the pack */
+        if (lattice_n < 0) { fprintf(stderr, "gram_lattice: %s\n", rqae_hip_last_error()); return 3; }
+        rqae_hip_gram_options opts;
+        memset(&opts, 0xff, sizeof opts);                                     /* every field negative: the defaults */
+        opts.size = (int32_t)sizeof opts;
+        opts.pipe_chunk = -1;
+        if (lattice_n >= 2) opts.lean_levels = 5;                             /* the block is a lattice: no scan kernel behind the lattice form */
+        CHECK_RQAE(rqae_hip_encode_gram(gpacked, d, c, K, L, 1, x, RQAE_X_F32, n, levels, (float *)q, (int64_t *)idx, ws, &opts, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        if (dump(dir, "idx_gram.bin", idx, (size_t)n * levels * sizeof(int64_t)) || dump(dir, "q_gram.bin", q, (size_t)n * d * f)) {
+            fprintf(stderr, "cannot write outputs\n");
+            return 7;
+        }
+        snprintf(path, sizeof path, "%s/lattice.txt", dir);
+        FILE *lf = fopen(path, "w");
+        if (!lf) return 7;
+        fprintf(lf, "%d\n", lattice_n);
+        fclose(lf);
+        /* an options struct of another size is refused, not misread */
+        opts.size = 8;
+        if (rqae_hip_encode_gram(gpacked, d, c, K, L, 1, x, RQAE_X_F32, n, levels, (float *)q, (int64_t *)idx, ws, &opts, stream) == 0) {
+            fprintf(stderr, "a short options struct was not refused\n");
+            return 6;
+        }
+    }
     printf("host_smoke ok: d=%d c=%d K=%d L=%d n=%d levels=%d\n", d, c, K, L, n, levels);
     return 0;
 }

@@ -727,6 +727,14 @@ def test_c_abi_from_a_c_program(tmp_path):
     q_o, idx_o = oracle.forward(x, w)
     assert np.array_equal(idx, idx_o) and np.array_equal(q, q_o)
     assert np.array_equal(dec, oracle.decode(idx_o, w))
+    # the matrix-core arm from the same C program: the FSQ lattice is found (n = 4), the call with lean_levels = 5 gives the oracle's
+    # codes but for low-margin tokens (SURVEY 8(c) Tier 2) and the reconstruction within 1e-5
+    assert (tmp_path / "lattice.txt").read_text().strip() == str(cfg["codebook_size"])
+    idx_g = np.fromfile(tmp_path / "idx_gram.bin", dtype=np.int64).reshape(n, L)
+    q_g = np.fromfile(tmp_path / "q_gram.bin", dtype=np.float32).reshape(n, d)
+    same = (idx_g == idx_o).all(axis=1)
+    assert same.sum() >= n - 1
+    assert rel_err(q_g[same], q_o[same]) < RTOL
 
 
 def test_subfeature_sims_scaled_as_the_server_keeps_them():

@@ -771,7 +771,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
             if (nstg > 1) issueC(1, 1);
             constexpr int PCS = (F_ETS * NKS) / F_NW;     // W_out pieces per wave and stage
             static_assert((F_ETS * NKS) % F_NW == 0, "whole pieces per wave");
-            constexpr int NST = 16;                       // stores per wave and stage pair
+            constexpr int NST = MODE == 6 ? 8 : 16;       // stores per wave and stage pair (MODE 6: 16 bytes = 8 two-byte elements per lane)
             int slot = 0;
             f32x4 accC[2 * F_ETS][A_TT];
             // a wave whose 32 rows and 128-element column blocks all exist issues exactly NST stores per pair (the waits count
@@ -844,37 +844,49 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                                     for (int t = 0; t < 2 * F_ETS; ++t) *reinterpret_cast<f32x4 *>(trb + (n & 7) * F_TRS + t * 64 + 16 * g) = accC[t][T];
                                 }
                                 wave_sync_lds();
+                                if constexpr (MODE == 6) {
+                                    // RQAE.hook's way back (rqae/model.py:284-289, rqae/llm.py:68-73): new = (q / (1 + w)) / rs, BOS rows keep
+                                    // the layer's own values, the result goes over the layer output in its dtype.  Two multiplications by
+                                    // reciprocals instead of the reference's two divisions (this arm is Tier 2; the difference is below the
+                                    // fp16 / bf16 rounding that follows).  A lane takes 8 consecutive elements (16 bytes out: 8-byte stores run
+                                    // at 0.5-0.7 of the 16-byte rate), 16 lanes a 128-element row, an instruction 4 rows; a BOS row's store
+                                    // goes to the dump rows: the store count stays static.
+                                    const int el8 = e0 * F_ETS * 16 + 8 * (lane & 15);
+#pragma unroll
+                                    for (int i = 0; i < 2; ++i) {
+                                        const int rr = 4 * i + (lane >> 4);
+                                        const int row = 16 * T + 8 * hh + rr;
+                                        const f32x4 va = *reinterpret_cast<const f32x4 *>(trb + rr * F_TRS + (lane & 15) * 32);
+                                        const f32x4 vb = *reinterpret_cast<const f32x4 *>(trb + rr * F_TRS + (lane & 15) * 32 + 16);
+                                        if (fullw || (tw0 + row < tile_end && el8 < p.d)) {
+                                            const float r = __shfl(irs_tok, row);
+                                            const f32x4 wa = *reinterpret_cast<const f32x4 *>(smem + bias_bytes + (size_t)el8 * 4);
+                                            const f32x4 wb8 = *reinterpret_cast<const f32x4 *>(smem + bias_bytes + (size_t)el8 * 4 + 16);
+                                            float o[8];
+#pragma unroll
+                                            for (int q = 0; q < 4; ++q) { o[q] = va[q] * wa[q] * r; o[4 + q] = vb[q] * wb8[q] * r; }
+                                            u32x4 pk;
+                                            if (p.hs_dtype == RQAE_X_F16) {
+                                                typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+#pragma unroll
+                                                for (int q = 0; q < 4; ++q) pk[q] = __builtin_bit_cast(unsigned, h2{(_Float16)o[2 * q], (_Float16)o[2 * q + 1]});
+                                            } else {
+                                                typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+#pragma unroll
+                                                for (int q = 0; q < 4; ++q) pk[q] = __builtin_bit_cast(unsigned, b2{(__bf16)o[2 * q], (__bf16)o[2 * q + 1]});
+                                            }
+                                            const bool bos = (bosmask >> row) & 1ull;
+                                            char *dst = bos ? reinterpret_cast<char *>(p.dump) + lane * 16
+                                                            : static_cast<char *>(p.hs_out) + ((size_t)(tw0 + row) * p.d + el8) * 2;
+                                            *reinterpret_cast<u32x4 *>(dst) = pk;
+                                        }
+                                    }
+                                } else {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
                                     const int rr = 2 * i + (lane >> 5);
                                     const f32x4 v = *reinterpret_cast<const f32x4 *>(trb + rr * F_TRS + (lane & 31) * 16);
                                     const int row = 16 * T + 8 * hh + rr;
-                                    if constexpr (MODE == 6) {
-                                        // RQAE.hook's way back (rqae/model.py:284-289, rqae/llm.py:68-73): new = (q / (1 + w)) / rs, BOS rows keep
-                                        // the layer's own values, the result goes over the layer output in its dtype.  Two multiplications by
-                                        // reciprocals instead of the reference's two divisions (this arm is Tier 2; the difference is below the
-                                        // fp16 / bf16 rounding that follows).  A BOS row's store goes to the dump rows: the store count stays static.
-                                        if (fullw || (tw0 + row < tile_end && el0 < p.d)) {
-                                            const float r = __shfl(irs_tok, row);
-                                            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(smem + bias_bytes + (size_t)el0 * 4);
-                                            const float o0 = v[0] * w4[0] * r, o1 = v[1] * w4[1] * r, o2 = v[2] * w4[2] * r, o3 = v[3] * w4[3] * r;
-                                            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-                                            u32x2 pk;
-                                            if (p.hs_dtype == RQAE_X_F16) {
-                                                typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-                                                pk[0] = __builtin_bit_cast(unsigned, h2{(_Float16)o0, (_Float16)o1});
-                                                pk[1] = __builtin_bit_cast(unsigned, h2{(_Float16)o2, (_Float16)o3});
-                                            } else {
-                                                typedef __attribute__((ext_vector_type(2))) __bf16 b2;
-                                                pk[0] = __builtin_bit_cast(unsigned, b2{(__bf16)o0, (__bf16)o1});
-                                                pk[1] = __builtin_bit_cast(unsigned, b2{(__bf16)o2, (__bf16)o3});
-                                            }
-                                            const bool bos = (bosmask >> row) & 1ull;
-                                            char *dst = bos ? reinterpret_cast<char *>(p.dump) + lane * 8
-                                                            : static_cast<char *>(p.hs_out) + ((size_t)(tw0 + row) * p.d + el0) * 2;
-                                            *reinterpret_cast<u32x2 *>(dst) = pk;
-                                        }
-                                    } else
 #ifdef FQ_NOSTORE   /* tools build: the reconstruction is computed and transposed but not stored */
                                     if (p.n_tokens < 0)
 #else
@@ -883,6 +895,7 @@ __global__ __launch_bounds__(F_NW * 64) void gram_fused_kernel(FusedParams p)
                                         // non-temporal: 2.4 GB written once.  Left in L2 / MALL as dirty lines they are written back under the
                                         // next kernel's reads (the projection ran 0.27-0.29 ms behind plain stores, 0.25 behind these)
                                         __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(orow + (unsigned)(row * p.d + el0)));
+                                }
                                 }
                                 wave_sync_lds();
                             }

@@ -203,6 +203,9 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
  *                                last pass, in milliseconds
  */
 int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared);
+/* one call with `levels` levels: the codes can always be had on a supported shape; the reconstruction (want_recon != 0) needs one of
+ * the instantiated reconstruction kernels (32 levels at c = 4, 24 at c = 5, 16 at 6 <= c <= 13) */
+int rqae_hip_encode_gram_supported(int d, int c, int K, int L, int codebook_shared, int levels, int want_recon);
 size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared);
 int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
                        const float *codebook, const float *w_out, const float *b_out, int codebook_shared,

@@ -41,6 +41,7 @@ SYMBOLS = (
     "rqae_hip_subfeature_sims",
     "rqae_hip_kernel_info",
     "rqae_hip_gram_supported",
+    "rqae_hip_encode_gram_supported",
     "rqae_hip_gram_packed_bytes",
     "rqae_hip_gram_pack",
     "rqae_hip_gram_lattice",
@@ -128,6 +129,8 @@ def lib():
     L.rqae_hip_kernel_info.restype = i
     L.rqae_hip_gram_supported.argtypes = [i, i, i, i, i]
     L.rqae_hip_gram_supported.restype = i
+    L.rqae_hip_encode_gram_supported.argtypes = [i, i, i, i, i, i, i]
+    L.rqae_hip_encode_gram_supported.restype = i
     L.rqae_hip_gram_packed_bytes.argtypes = [i, i, i, i, i]
     L.rqae_hip_gram_packed_bytes.restype = sz
     L.rqae_hip_gram_pack.argtypes = [vp, i, i, i, i, vp, vp, vp, vp, vp, i, vp, vp]
@@ -244,6 +247,12 @@ def encode(packed, dims, x2d: torch.Tensor, levels: int, want_recon: bool = True
 def gram_supported(dims, codebook_shared: bool) -> bool:
     d, c, K, L_ = dims
     return bool(lib().rqae_hip_gram_supported(d, c, K, L_, int(bool(codebook_shared))))
+
+
+def encode_gram_supported(dims, codebook_shared: bool, levels: int, want_recon: bool = True) -> bool:
+    """One call with ``levels`` levels on the matrix-core arm (the reconstruction has its own depth limit)."""
+    d, c, K, L_ = dims
+    return bool(lib().rqae_hip_encode_gram_supported(d, c, K, L_, int(bool(codebook_shared)), int(levels), int(bool(want_recon))))
 
 
 def gram_pack(w_in, b_in, codebook, w_out, b_out, codebook_shared: bool, in_scale: torch.Tensor | None = None) -> torch.Tensor:

@@ -1466,6 +1466,18 @@ int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared)
     return ((g.CP <= 5 && levels_resident_ok(g)) || levels_stream_ok(g) || (g.shared_cb && levels_wide_ok(g)) || levels_free_ok(g)) ? 1 : 0;
 }
 
+// Can one call with `levels` levels run on this arm?  The codes always can (on a supported shape); the reconstruction needs one of
+// the instantiated reconstruction kernels: up to 24 k-steps of 32 slots (6 c slots per level: 32 levels at c = 4, 24 at c = 5), or
+// the wide kernel's 16 levels.
+int rqae_hip_encode_gram_supported(int d, int c, int K, int L, int codebook_shared, int levels, int want_recon)
+{
+    if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared) || levels < 1 || levels > L) return 0;
+    if (!want_recon) return 1;
+    const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
+    if (g.CP == 13) return levels <= 16 ? 1 : 0;
+    return recon_nks_template(nks_recon(g, levels)) != 0 ? 1 : 0;
+}
+
 size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared)
 {
     if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared)) {

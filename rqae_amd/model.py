@@ -275,15 +275,16 @@ class RQAE(nn.Module):
             return self._pack(used)
 
     # ------------------------------------------------------------ matrix-core arm
-    def _use_gram(self, n_tokens: int, levels: int) -> bool:
+    def _use_gram(self, n_tokens: int, levels: int, want_recon: bool = True) -> bool:
         if self.arm == "exact":
             return False
         # FSQ lattices: one codebook for every level; any other method: one per level, streamed level by level
-        ok = _native.gram_supported(self._dims(), self.quantization_method in _FSQ_METHODS)
+        ok = _native.encode_gram_supported(self._dims(), self.quantization_method in _FSQ_METHODS, levels, want_recon)
         if self.arm == "gram":
             if not ok:
-                raise RuntimeError(f"rqae_amd: arm='gram' does not serve shape (d, c, K, L) = {self._dims()} "
-                                   "(include/rqae_hip.h: rqae_hip_gram_supported); use arm='exact' or 'auto'")
+                raise RuntimeError(f"rqae_amd: arm='gram' does not serve shape (d, c, K, L) = {self._dims()} at {levels} levels"
+                                   f"{' with reconstruction' if want_recon else ''} "
+                                   "(include/rqae_hip.h: rqae_hip_encode_gram_supported); use arm='exact' or 'auto'")
             return True
         return ok and n_tokens >= self.GRAM_MIN_TOKENS
 
@@ -525,7 +526,7 @@ class RQAE(nn.Module):
         if d != self._dim:
             raise RuntimeError(f"RQAE.encode: last dim {d} != model dim {self._dim}")
         x2d = x.reshape(B * S, d).contiguous()
-        if self._use_gram(B * S, levels):
+        if self._use_gram(B * S, levels, want_recon=False):
             _, idx = self._encode_gram(x2d, levels, False)
         else:
             _, idx = _native.encode(self._packed_for_encode(levels), self._dims(), x2d, levels, want_recon=False)
@@ -565,7 +566,7 @@ class RQAE(nn.Module):
         if idx.dtype not in (torch.int64, torch.int32, torch.uint16):
             idx = idx.long()
         idx = idx.contiguous()
-        if (all(keep) and self.quantization_method in _FSQ_METHODS and self._use_gram(B * S, NQ)
+        if (all(keep) and self.quantization_method in _FSQ_METHODS and self._use_gram(B * S, NQ, want_recon=False)
                 and _native.decode_gram_supported(self._dims(), True, NQ)):
             # the matrix-core arm's reconstruction kernel fed by the codes: same sum within 1e-6 relative, HBM-write-bound
             out = _native.decode_gram(self.gram_packed_weights(), self._dims(), True, idx)

@@ -398,6 +398,29 @@ def test_gram_wide_shared_lattices_between_c6_and_c12(cd, cs, levels, n):
     check_tier2(xs3, w, q3, i3, levels=max(1, levels // 2))
 
 
+def test_depth_beyond_the_reconstruction_kernels():
+    """The reconstruction kernels serve up to 24 k-steps (32 levels at c = 4, 24 at c = 5): a deeper call says so when the arm is
+    forced, takes the exact arm under arm='auto', and the codes alone (RQAE.encode) still come from the matrix-core arm."""
+    cfg = dict(dim=256, codebook_dim=4, codebook_size=5, num_quantizers=33)
+    w = synth.weights(5, cfg["dim"], 4, 33, 5)
+    x = synth.activations(3, 700, cfg["dim"])
+    assert _native.encode_gram_supported((256, 4, 625, 33), True, 32) and not _native.encode_gram_supported((256, 4, 625, 33), True, 33)
+    assert _native.encode_gram_supported((256, 4, 625, 33), True, 33, want_recon=False)
+    m = make_model(cfg, w, "gram")
+    with pytest.raises(RuntimeError, match="33 levels with reconstruction"):
+        run(m, x, torch.float32)
+    q, idx, xs = run(m, x, torch.float32, max_layers=32)
+    check_tier2(xs, w, q, idx, levels=32)
+    with torch.inference_mode():
+        codes = m.encode(torch.from_numpy(x).to(DEV).view(1, 700, -1))       # codes only: all 33 levels
+    ma = make_model(cfg, w, "auto")
+    ma.GRAM_MIN_TOKENS = 1
+    qa, ia, _ = run(ma, x, torch.float32)                                     # auto: the exact arm at this depth
+    q_o, idx_o = oracle.forward(x, w)
+    assert np.array_equal(ia, idx_o) and np.array_equal(qa, q_o)
+    assert (codes.cpu().numpy().reshape(700, -1) != idx_o).any(axis=1).sum() <= 2
+
+
 def test_gram_c4_wide_codebook_depth_16():
     """BASELINE configs[3] as stated: d 3584, c 13, K 8192 = 2^13, depth 16 on the matrix cores (csrc/gram_wide.hpp: three k-steps
     per cosine contraction, the 1.5 MB codebook image streamed through LDS, four level groups of four levels, reconstruction with

@@ -64,7 +64,7 @@ GRAM_MFMA_FLOPS_PER_TOKEN = 2 * D * 48 * 3 + L * 2 * K * 32 + 2 * D * 256
 
 PROFILE_ROUND = "r03"     # profiles/<round>_traffic.json, <round>_pmc_summary.json: the committed counter passes of this round
 
-KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "gram_wide.hpp", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
+KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "gram_wide.hpp", "gram_recon3.hpp", "gram_small.hpp", "recon3.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
 
 
 def sources_hash():
@@ -75,27 +75,49 @@ def sources_hash():
     return h.hexdigest()[:16]
 
 
-def synth_batch(torch, n_tokens, device, seed):
+def synth_batch(torch, n_tokens, device, seed, d=None, dtype=None):
     """Gemma-like residual rows generated ON DEVICE (no H2D in the bench): N(0,1) x heavy-tailed
-    channel scale, 4 massive channels, RMS-normalised, x (1+w); rounded to bf16."""
+    channel scale, 4 massive channels, RMS-normalised, x (1+w); rounded to bf16 (or kept fp32)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    d = CFG["dim"]
+    d = d or CFG["dim"]
+    dtype = dtype or torch.bfloat16
     scale = 0.3 + torch.randn(d, device=device, generator=g) ** 2
     scale[torch.randperm(d, device=device, generator=g)[:4]] *= 30.0
     w = 0.1 * torch.randn(d, device=device, generator=g)
-    x = torch.empty(n_tokens, d, device=device, dtype=torch.bfloat16)
+    x = torch.empty(n_tokens, d, device=device, dtype=dtype)
     step = 32768
     for s in range(0, n_tokens, step):
         z = torch.randn(min(step, n_tokens - s), d, device=device, generator=g) * scale
         z = z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6) * (1.0 + w)
-        x[s:s + z.shape[0]] = z.to(torch.bfloat16)
+        x[s:s + z.shape[0]] = z.to(dtype)
     return x
 
 
-def cpu_baseline(w, target_seconds=12.0):
+def cpu_baseline_reference_ops(w, n=32768):
+    """SURVEY 8(d)'s CPU baseline: the reference's operator sequence (rqae/model.py:199-230 -- per level addmm, norm, div,
+    [N,K] matmul, argmax, gather, straight-through sum, addmm, sub, add) through PyTorch-CPU ops on all host cores, ONE pass over
+    N = 32768 tokens of the same workload (oracle/torch_ops.py: bit-equal to the reference captures, tests/test_oracle_golden.py)."""
+    import torch
+    from oracle import torch_ops
+    from rqae_amd import synth
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = synth.round_to_bf16(synth.activations(1001, n, CFG["dim"]))
+    torch_ops.forward(x[:2048], w)        # warm: thread pool, allocator
+    t0 = time.perf_counter()
+    torch_ops.forward(x, w)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "reference-ops",
+            "sample": f"1 x {n} tokens of the same workload (bf16-rounded synthetic rows as fp32, d=2304 K=1024 depth=8, codes + "
+                      f"reconstruction) through the reference's own PyTorch-CPU operator sequence (oracle/torch_ops.py restates "
+                      f"rqae/model.py:199-230 op for op; torch.set_num_threads({cores}) = os.cpu_count()), {dt:.1f} s"}
+
+
+def cpu_baseline(w, target_seconds=8.0):
     """The CPU oracle (a port of the reference's math, pinned to its golden vectors) timed on
-    this host's cores on a bounded sample of the same workload (~10-15 s of CPU work)."""
+    this host's cores on a bounded sample of the same workload (~10 s of CPU work)."""
     import oracle
     from rqae_amd import synth
 
@@ -150,6 +172,132 @@ def parity_check(np, torch, model, x, w, gram, codes_only, n_check=65536):
     return out
 
 
+# ---- the other BASELINE configs, timed in the same process after the C2 legs ---------------------------
+# (name, synth config, tokens, x dtype, what it is)
+CONFIG_LEGS = [
+    ("C4/bf16", "C4", 65536, "bf16", "configs[3]: d=3584, K=8192 (c=13), depth=16, 65536 tokens, bf16 in"),
+    ("C4/f32", "C4", 65536, "f32", "configs[3] with fp32 activations"),
+    ("C5/bf16", "C5", 262144, "bf16", "configs[4]'s shape: d=2304, K=4096 (c=4), depth=32, 262144 tokens, bf16 in (fp32-accurate operands; "
+                                      "the fp8 codebook was measured and rejected, DESIGN.md 12.6)"),
+    ("P16/bf16", "P", 262144, "bf16", "released shape cut to depth 16: d=2304, K=625 (c=4, n=5), 262144 tokens, bf16 in"),
+]
+
+
+def algorithmic_per_token(d, c, K, L, x_bytes):
+    """bytes = x in + fp32 reconstruction + int64 codes; flops = L (2dc + 2cK + 2cd + 2d)."""
+    return d * x_bytes + d * 4 + L * 8, L * (2 * d * c + 2 * c * K + 2 * c * d + 2 * d)
+
+
+def issued_mfma_flops_per_token(d, c, K, L, dtype, lattice):
+    """Matrix-instruction flops the matrix-core arm issues per token (DESIGN.md sections 9, 12, 13): every fp32 operand as exact
+    low-precision pieces -- projection: W_in pieces x x pieces over d x (level groups x 16-wide output tiles); the cosine scan (none on
+    an FSQ lattice codebook); reconstruction over the k-slots of the straight-through values' pieces."""
+    cp = 4 if c <= 4 else 5 if c == 5 else 13
+    gl = 8 if cp <= 8 else 4
+    gp = (gl * cp + 15) // 16 * 16
+    nlg = (L + gl - 1) // gl
+    xp = {"bf16": 3, "f16": 6, "f32": 6}[dtype]           # piece products per weight fragment
+    proj = 2 * d * nlg * gp * xp
+    nkc = (6 * cp + 31) // 32
+    scan = 0 if lattice else L * 2 * ((K + 15) // 16 * 16) * 32 * nkc
+    # reconstruction: gram_recon3_kernel -- two fp16 pieces per value, three products, k-steps of 16 values (instantiated depths)
+    ks = (L * c + 15) // 16
+    ks_t = next((v for v in (2, 3, 4, 8, 13) if ks <= v), None)
+    if ks_t is not None:
+        recon = 2 * d * 16 * ks_t * 3
+    else:
+        full, rem = divmod(L, gl)
+        gs = (6 * cp * gl + 31) // 32 * 32
+        recon = 2 * d * (full * gs + (6 * cp * rem + 31) // 32 * 32)
+    return proj + scan + recon
+
+
+def config_leg(np, torch, device, name, cfg_name, tokens, dtype, what, steps=10, warmup=3, n_check=4096, options=None,
+               free_codebooks=False, arm="gram"):
+    """One BASELINE config through the product path: `steps` timed forwards (HIP events on the launch stream, synchronised both
+    sides), the per-kernel split, both roofline fractions and a parity count against the oracle on the first `n_check` tokens."""
+    import oracle
+    from rqae_amd import RQAE, _native, synth
+
+    cfg = dict(synth.CONFIGS[cfg_name])
+    if free_codebooks:
+        rows = cfg["codebook_size"] ** cfg["codebook_dim"]
+        w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], free_codebook_rows=rows)
+        cfg.update(codebook_size=rows, quantization_method="vq")
+    else:
+        w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    model = RQAE(**cfg, arm=arm).eval()
+    model.load_state_dict(synth.state_dict_from_weights(w), strict=True)
+    model = model.to(device)
+    if options is not None:
+        model.gram_options = options
+    d, c, K, L_ = model._dims()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    x = synth_batch(torch, tokens, device, seed=4321, d=d, dtype=tdt).view(1, tokens, d)
+    evs = []
+    with torch.inference_mode():
+        for _ in range(warmup):
+            model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            q, idx = model(x)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    ev_ms = [a.elapsed_time(b) for a, b in evs]
+    ms = wall / steps * 1e3
+    bytes_tok, flops_tok = algorithmic_per_token(d, c, K, L_, 2 if dtype == "bf16" else 4)
+    tps = tokens / (ms * 1e-3)
+    out = {"what": what, "tokens": tokens, "dtype_in": dtype, "steps": steps, "warmup": warmup, "ms": ms,
+           "ms_events": {"min": float(np.min(ev_ms)), "median": float(np.median(ev_ms)), "max": float(np.max(ev_ms))},
+           "value": tps, "unit": "tokens/s", "bytes_per_token": bytes_tok, "algorithmic_flops_per_token": flops_tok}
+    hbm_frac = tps * bytes_tok / 1e9 / PEAK_HBM_GBS
+    roof = {"hbm_frac": hbm_frac, "hbm_GBs": tps * bytes_tok / 1e9,
+            "algorithmic_flops_frac_of_bf16_peak": tps * flops_tok / 1e12 / PEAK_BF16_TFLOPS}
+    shared = not free_codebooks
+    if arm != "exact" and shared:
+        try:
+            with torch.inference_mode():
+                ph = [_native.encode_gram_phases(model.gram_packed_weights(), model._dims(), x.view(tokens, -1), L_, options=options)
+                      for _ in range(3)]
+            out["kernel_ms"] = dict(zip(["project", "levels", "reconstruct"], [float(np.median(v)) for v in zip(*ph)]))
+        except Exception as e:
+            out["kernel_ms"] = f"unavailable: {e}"
+        lattice = getattr(model.gram_packed_weights(), "lattice_n", 0) >= 2 and (options is None or options.lean_levels >= 4 or options.lean_levels < 0)
+        issued = issued_mfma_flops_per_token(d, c, K, L_, dtype, lattice)
+        roof["mfma_issued_flops_per_token"] = issued
+        roof["mfma_frac"] = tps * issued / 1e12 / PEAK_BF16_TFLOPS
+    else:
+        roof["mfma_frac"] = None
+    fr = [(roof["hbm_frac"], "hbm"), (roof.get("mfma_frac") or 0.0, "mfma")]
+    roof["frac"], roof["bound"] = max(fr)
+    out["roofline"] = roof
+    # parity: the first n_check tokens, product path vs oracle (SURVEY 8(c) Tier 2)
+    n = min(n_check, tokens)
+    if free_codebooks:
+        wchk = dict(w, codebook=model._codebook_used.float().cpu().numpy()) if hasattr(model, "_codebook_used") else w
+    else:
+        wchk = w
+    xf = x[:, :n].float().cpu().numpy().reshape(n, -1)
+    q_o, idx_o, mg = oracle.forward(xf, wchk, want_margins=True)
+    ig = idx[0, :n].cpu().numpy().reshape(n, -1)
+    qg = q[0, :n].cpu().numpy().reshape(n, -1)
+    differ = (ig != idx_o).any(axis=1)
+    bad = differ & (np.nanmin(mg, axis=1) >= 1e-5)
+    same = ~differ
+    rel = np.abs(qg[same] - q_o[same]).max(axis=1) / np.abs(q_o[same]).max(axis=1)
+    out["parity"] = {"tokens_checked": int(n), "tokens_with_other_codes": int(differ.sum()), "mismatch_at_margin_ge_1e-5": int(bad.sum()),
+                     "recon_max_rel_err": float(rel.max()) if rel.size else 0.0,
+                     "ok": bool(bad.sum() == 0 and (not rel.size or rel.max() < 1e-5))}
+    del model, x, q, idx
+    torch.cuda.empty_cache()
+    return out
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -189,6 +337,7 @@ def main():
                     help="untimed run of the same step before the warm-up steps (disclosed as spinup_ms in the line); 0 = none")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the 524288- and 1048576-token legs")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle check of a 65536-token slice of the timed batch")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configs, N = 1 only)")
     ap.add_argument("--stub", action="store_true", help="CPU/gloo rehearsal of the multi-rank orchestration (tests only)")
     args = ap.parse_args()
 
@@ -400,8 +549,33 @@ def main():
                             **legs}
         if not args.no_parity:
             line["parity"] = parity_check(np, torch, model, x, w, gram, args.codes_only)
+        if world == 1 and not args.no_configs and not args.tokens and not args.codes_only and args.arm == "gram":
+            cfgs = {"note": "the other BASELINE configs through the same product path in this process, after the C2 legs: `ms` = wall time "
+                            "per forward over `steps` forwards bracketed by torch.cuda.synchronize(); roofline.frac = the larger of hbm_frac "
+                            "(algorithmic bytes / s over 8 TB/s) and mfma_frac (matrix-instruction flops issued / s over the dense bf16 peak)"}
+            del x
+            torch.cuda.empty_cache()
+            for name, cname, ntok, dt, what in CONFIG_LEGS:
+                try:
+                    cfgs[name] = config_leg(np, torch, device, name, cname, ntok, dt, what)
+                except Exception as e:      # a leg that fails is reported, never hidden
+                    cfgs[name] = {"what": what, "error": f"{type(e).__name__}: {e}"}
+            try:
+                cfgs["C2/scan"] = config_leg(np, torch, device, "C2/scan", "C2", 262144, "bf16",
+                                             "configs[1]'s shape with the codebook SCANNED on the matrix cores (lean_levels=2: the path for any "
+                                             "shared codebook that is not an FSQ lattice)", options=_native.gram_options(lean_levels=2))
+            except Exception as e:
+                cfgs["C2/scan"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                cfgs["C2/vq"] = config_leg(np, torch, device, "C2/vq", "C2", 262144, "bf16",
+                                           "configs[1]'s shape with one learned codebook per level (quantization_method 'vq', renormalised in "
+                                           "place once per level as rqae/model.py:126-131,196 does)", free_codebooks=True)
+            except Exception as e:
+                cfgs["C2/vq"] = {"error": f"{type(e).__name__}: {e}"}
+            line["configs"] = cfgs
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w)
+            line["cpu_baseline"] = cpu_baseline_reference_ops(w)
+            line["cpu_baseline_port"] = cpu_baseline(w)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "../../include/rqae_hip.h"
+#include "recon3.h"
 
 extern __attribute__((visibility("hidden"))) __thread char rqae_g_err[512];   // __thread, not thread_local: no TLS init wrapper (a hidden weak _ZTH call crashes)
 
@@ -52,19 +53,7 @@ int gfail(const char *fmt, ...)
         if (e_ != hipSuccess) return gfail("%s: %s", #expr, hipGetErrorString(e_));      \
     } while (0)
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-// compile-time loop: the body is instantiated once per index (hipcc refuses to unroll the level loop by pragma)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
+#include "gram_small.hpp"
 
 constexpr int GRAM_MAGIC = 0x4752414d;  // "GRAM"
 constexpr int GRAM_MAX_L = 64;
@@ -78,6 +67,7 @@ constexpr int GRAM_MAX_C = 13;          // instantiated: CP = 4, 5 (resident / s
 // NKC  k-steps of the cosine contraction (6*CP slots)
 struct Geom {
     int d, c, K, L, CP, GL, GP, GS, NLG, NOG, KSA, NKC, KT, KTP, NET, NKSC, GB, shared_cb;
+    int KS3;                  // k-steps (16 values) of the fp16 reconstruction image (gram_recon3.hpp): L c values, tight
 };
 
 __host__ __device__ inline int cp_of(int c) { return c <= 4 ? 4 : c == 5 ? 5 : 13; }
@@ -100,6 +90,7 @@ __host__ __device__ inline Geom make_geom(int d, int c, int K, int L, int shared
     g.NET = d / 16;
     g.NKSC = g.NLG * (g.GS / 32);        // k-steps of the reconstruction at full depth
     g.GB = (g.CP * g.CP + 3) & ~3;       // floats per Gram block
+    g.KS3 = (L * c + 15) / 16;
     return g;
 }
 
@@ -116,11 +107,8 @@ __host__ __device__ inline int nks_recon(const Geom &g, int levels)
     return full * (g.GS / 32) + (6 * g.CP * rem + 31) / 32;
 }
 
-inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
-__host__ __device__ constexpr size_t pad1k(size_t v) { return (v + 1023) & ~size_t(1023); }
-
 struct GLayout {
-    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, total;
+    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, wout3_img, total;
 };
 
 GLayout make_glayout(const Geom &g)
@@ -135,6 +123,7 @@ GLayout make_glayout(const Geom &g)
     lo.cb_f32 = off;      off += al256(pad1k(sizeof(float) * ((size_t)lcb * g.K * g.c + 64 * g.c)));   // + slack: quad-row reads of pad rows; whole KiB: staged by 1-KiB LDS-DMA pieces
     lo.wout_img = off;    off += al256((size_t)g.NET * g.NKSC * 1024);
     lo.bias_prefix = off; off += al256(sizeof(float) * (size_t)g.L * g.d + 1024);                        // + 1 KiB: the fused kernel stages a row in whole 1-KiB pieces
+    lo.wout3_img = off;   off += al256(rqae_r3::image_bytes(g.d, g.c, g.L));                              // fp16 two-piece W_out image (gram_recon3.hpp)
     lo.total = off;
     return lo;
 }
@@ -143,7 +132,8 @@ struct GHeader {
     int magic, d, c, K, L, shared_cb;
     int lattice_n;            // n >= 2: the shared codebook is the FSQ lattice {linspace(-1, 1, n)}^c (gram_pack_lattice_kernel); else 0
     int lattice_miss[2];      // scratch of that check: rows that are not the unit-length lattice row / not the plain lattice row
-    int pad[55];
+    unsigned wout_maxbits;    // bits of max |W_out| (gram_pack_absmax_kernel): fixes the power-of-two scale of the fp16 image
+    int pad[54];
 };
 static_assert(sizeof(GHeader) == 256, "header");
 
@@ -575,34 +565,6 @@ __device__ __forceinline__ void xparts(const u32x4 (&raw)[XRaw<XT>::NLD], u32x4 
     XFrag<XT> f;
     if constexpr (XT == RQAE_X_F32) { f.raw0 = raw[0]; f.raw1 = raw[1]; } else { f.raw = raw[0]; }
     f.parts(o);
-}
-
-__device__ __forceinline__ const void *uniform_ptr(const void *p)
-{
-    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-    const unsigned long long u = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
-                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32);
-    return reinterpret_cast<const void *>(u);
-}
-
-// one 1-KiB LDS-DMA piece: lane i moves 16 bytes from g_uniform + 16 i to LDS byte address lds_addr + 16 i (M0 saved/restored)
-__device__ __forceinline__ void dma_piece(const void *g_uniform, unsigned lds_addr, unsigned lane_byte_off)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_byte_off), "s"(g_uniform), "s"(lds_addr)
-                 : "memory");
-}
-
-// the same piece with the non-temporal hint: the x stream is read once and should not push the weight images out of L2 / MALL
-__device__ __forceinline__ void dma_piece_nt(const void *g_uniform, unsigned lds_addr, unsigned lane_byte_off)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_byte_off), "s"(g_uniform), "s"(lds_addr)
-                 : "memory");
 }
 
 // ABL: compile-time ablation bits for tools/ builds (-DRQAE_GRAM_ABLATE; 0 in the product): 1 = no MFMAs, 2 = no weight
@@ -1278,7 +1240,8 @@ struct Tuning {
     int c_tt;            // reconstruct kernel: 16-token tiles per wave (2: 8 waves per workgroup, 1: 16 waves)
     long long chunk;     // tokens per pass
     int proj;            // projection kernel: 3 = phase A of the fused kernel (default for 2-byte x), 2 = pipelined register form, 1 = first form
-    int recon;           // reconstruction kernel: 2 = phase C of the fused kernel (default for one level group), 1 = weights-stationary form
+    int recon;           // reconstruction kernel: 3 = gram_recon3_kernel (fp16 two-piece operands, 32x32x16, 1-KiB store rows: the default wherever
+                         // the level chain hands over fp32 planes), 2 = phase C of the fused kernel (one level group), 1 = weights-stationary form
     long long pipe_chunk; // tokens per pass of the pipelined schedule (0: never pipeline)
     int cap_ab;          // pipelined schedule: CUs for projection + level chain; the reconstruction of the pass before takes the rest
     int fused;           // 1: one persistent kernel where the shape allows it, 0: always the three-kernel form
@@ -1296,7 +1259,7 @@ Tuning default_tuning()
     v.chunk = GRAM_CHUNK;
     v.c_tt = 2;
     v.proj = 3;
-    v.recon = 2;
+    v.recon = 3;
     v.fused = 0;
     v.pipe_chunk = 0;       // off: measured slower (profiles/r02_pipeline_trace.txt): the kernels are bound per CU, not by HBM
     v.cap_ab = 160;
@@ -1306,7 +1269,7 @@ Tuning default_tuning()
 #ifdef RQAE_GRAM_TOOLS
     static const Tuning env = [v]() mutable {
         if (const char *e = getenv("RQAE_GRAM_PROJ")) { const int a = atoi(e); v.proj = a >= 1 && a <= 3 ? a : 3; }
-        if (const char *e = getenv("RQAE_GRAM_RECON")) v.recon = atoi(e) == 1 ? 1 : 2;
+        if (const char *e = getenv("RQAE_GRAM_RECON")) { const int a = atoi(e); v.recon = a >= 1 && a <= 3 ? a : 3; }
         if (const char *e = getenv("RQAE_GRAM_FUSED")) v.fused = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_PIPE")) { const long long c = atoll(e); v.pipe_chunk = c <= 0 ? 0 : ((c + 255) & ~255LL); }
         if (const char *e = getenv("RQAE_GRAM_CAP_AB")) { const int c = atoi(e); if (c >= 8) v.cap_ab = c; }
@@ -1330,7 +1293,7 @@ int make_tuning(const rqae_hip_gram_options *o, Tuning &t)
     if (o->size != (int32_t)sizeof(rqae_hip_gram_options)) return gfail("gram options: size %d, this library expects %d", (int)o->size, (int)sizeof(rqae_hip_gram_options));
     if (o->fused >= 0) t.fused = o->fused != 0;
     if (o->pipe_chunk >= 0) t.pipe_chunk = o->pipe_chunk == 0 ? 0 : ((o->pipe_chunk + 255) & ~255LL);
-    if (o->proj > 3 || o->recon > 2 || o->lean_levels > 5) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
+    if (o->proj > 3 || o->recon > 3 || o->lean_levels > 5) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
     if (o->proj >= 1) t.proj = o->proj;
     if (o->recon >= 1) t.recon = o->recon;
     // 0..3 name a scan kernel; 4 = lattice form with the scan kernel behind it; 5 = lattice form alone (the caller has asked
@@ -1355,8 +1318,9 @@ int device_cus()
 
 struct GView {
     Geom g;
-    const uint16_t *win_img, *cb_img, *wout_img;
+    const uint16_t *win_img, *cb_img, *wout_img, *wout3_img;
     const float *kconst, *gneg, *cb_f32, *bias_prefix;
+    const unsigned *wout_maxbits;
 };
 
 // the header lives on the device; the caller passes (d, c, K, L) again and the geometry is recomputed
@@ -1373,6 +1337,8 @@ GView gview(const void *packed, int d, int c, int K, int L, int shared_cb)
     v.cb_f32 = reinterpret_cast<const float *>(b + lo.cb_f32);
     v.wout_img = reinterpret_cast<const uint16_t *>(b + lo.wout_img);
     v.bias_prefix = reinterpret_cast<const float *>(b + lo.bias_prefix);
+    v.wout3_img = reinterpret_cast<const uint16_t *>(b + lo.wout3_img);
+    v.wout_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, wout_maxbits));
     return v;
 }
 
@@ -1386,7 +1352,9 @@ inline long long pad64(long long n) { return (n + 63) & ~63LL; }
 size_t cv_row_bytes(const Geom &g, int levels)
 {
     const size_t rows = (size_t)nks_recon(g, levels) * 64, f32 = (size_t)8 * g.CP * 4;
-    return rows > f32 ? rows : f32;
+    const size_t planes = (size_t)levels * (g.CP <= 5 ? g.CP : 16) * 4;      // fp32 planes of every level (gram_recon3_kernel's input)
+    const size_t a = rows > f32 ? rows : f32;
+    return a > planes ? a : planes;
 }
 
 size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
@@ -1474,6 +1442,7 @@ int rqae_hip_encode_gram_supported(int d, int c, int K, int L, int codebook_shar
     if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared) || levels < 1 || levels > L) return 0;
     if (!want_recon) return 1;
     const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
+    if (rqae_r3::supported(d, c, levels) && (g.CP == 13 || levels <= 8)) return 1;      // gram_recon3_kernel behind the planes of the wide / lean level chains
     if (g.CP == 13) return levels <= 16 ? 1 : 0;
     return recon_nks_template(nks_recon(g, levels)) != 0 ? 1 : 0;
 }
@@ -1530,6 +1499,8 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
     hipLaunchKernelGGL(gram_pack_bias_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, s, g, b_out,
                        reinterpret_cast<float *>(b + lo.bias_prefix));
     G_TRY(hipGetLastError());
+    // the fp16 two-piece image of W_out (gram_recon3.hpp): its power-of-two scale follows from max |W_out|, found on the device
+    if (int rc = rqae_r3::pack(b + lo.wout3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, wout_maxbits)), d, c, L, w_out, s)) return rc;
     return 0;
 }
 
@@ -1584,7 +1555,6 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     const int nks = nks_recon(g, levels);
     const int nks_t = recon_nks_template(nks);
     const bool wide = g.CP == 13;
-    if (q_out && !nks_t && !wide) return gfail("encode_gram: reconstruction with %d k-steps is not instantiated (codes only: pass q_out = NULL)", nks);
     const size_t xs = x_dtype == RQAE_X_F32 ? 4 : 2;
     const int ncu = device_cus();
 
@@ -1636,12 +1606,23 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
 #else
     // one pass = projection + level chain (phaseAB) and reconstruction (phaseC) of the tokens [t0, t0 + nt); `ncu` caps the
     // persistent grids, `cvimg` is the operand-row buffer the two halves share
-    const bool recon2_ok = tuning().recon == 2 && g.CP <= 5 && levels <= 8 && d % 16 == 0 &&
+    const bool recon2_ok = tuning().recon >= 2 && g.CP <= 5 && levels <= 8 && d % 16 == 0 &&
         pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW <= 160 * 1024;
-    // one level group: the lean level chain hands fp32 straight-through values to the reconstruction (which splits them)
-    const bool lev2 = tuning().lev2 && g.CP <= 5 && levels <= 8 && g.shared_cb && g.NKC == 1 && lev2_lds_bytes(c, K) <= 160 * 1024 && (!q_out || recon2_ok);
     // inv1pw != NULL: the hook's way back folded into the reconstruction's stores (gram_fused_kernel MODE 6): x is patched in place
     const bool patch = inv1pw != nullptr;
+    // gram_recon3_kernel (fp16 two-piece operands): any shape whose values fit 16 k-steps, fed by fp32 planes
+    const bool r3_want = q_out && !patch && tuning().recon == 3 && rqae_r3::supported(d, c, levels);
+    // one level group: the lean level chain hands fp32 straight-through values to the reconstruction (which splits them)
+    const bool lev2 = tuning().lev2 && g.CP <= 5 && levels <= 8 && g.shared_cb && g.NKC == 1 && lev2_lds_bytes(c, K) <= 160 * 1024 && (!q_out || recon2_ok || r3_want);
+    // FSQ lattice codebooks: the lattice form first (it returns at once unless the block's header names a lattice), the scan kernel of
+    // the shape behind it (it returns at once if the header does)
+    const int *lat = tuning().lattice && g.shared_cb && (g.CP > 5 || (size_t)K * c * 4 <= 150 * 1024) ? reinterpret_cast<const int *>(static_cast<const char *>(packed) + offsetof(GHeader, lattice_n)) : nullptr;
+    // narrow codebooks outside the lean path (several level groups, or a codebook too large for the scan's tables): the scan kernels
+    // write bf16 operand rows, so fp32 planes for every level exist only when the caller vouches for a lattice (lean_levels = 5: the
+    // lattice form runs alone)
+    const bool lat_planes = r3_want && !wide && !lev2 && lat && tuning().lattice == 2;
+    const bool r3_go = r3_want && (wide || lev2 || lat_planes);
+    if (q_out && !r3_go && !nks_t && !wide) return gfail("encode_gram: reconstruction with %d k-steps is not instantiated (codes only: pass q_out = NULL)", nks);
     if (patch && !(inv_rms && recon2_ok && lev2 && patch_S >= 1))
         return gfail("encode_gram_gemma_patch: needs the folded norm, one level group (levels <= 8) and the token-stationary reconstruction");
     auto phaseAB = [&](long long t0, long long nt, hipStream_t s, int ncu, unsigned *cvimg, bool mark, bool strict) -> int {
@@ -1740,10 +1721,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         }
         if (mark) G_TRY(hipEventRecord(ev[1], s));
         // ---- B
-        // FSQ lattice codebooks: the lattice form first (it returns at once unless the block's header names a lattice), the scan
-        // kernel of the shape behind it (it returns at once if the header does).  Both write the same outputs in the same formats:
-        // fp32 planes for the lean / wide reconstructions, operand rows otherwise.
-        const int *lat = tuning().lattice && g.shared_cb && (g.CP > 5 || (size_t)K * c * 4 <= 150 * 1024) ? reinterpret_cast<const int *>(static_cast<const char *>(packed) + offsetof(GHeader, lattice_n)) : nullptr;
+        // The lattice form and the scan kernel behind it write the same outputs in the same formats: fp32 planes for the lean / wide
+        // reconstructions, operand rows otherwise.
         if (lat) {
             LevParams pl;
             pl.P = P; pl.kconst = v.kconst; pl.gneg = v.gneg; pl.cb_img = v.cb_img; pl.cb_f32 = v.cb_f32; pl.cvimg = cvimg;
@@ -1769,6 +1748,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
 #define LATK(CPV, MV, IV) (ceq ? go(gram_levels_wide_kernel<CPV, 4, MV, IV, true, true>) : go(gram_levels_wide_kernel<CPV, 4, MV, IV, true, false>))
             if (wide) rc = ceq ? go(gram_levels_wide_kernel<13, 8, true, false, true, true>) : go(gram_levels_wide_kernel<13, 8, true, false, true, false>);
             else if (lev2) rc = g.CP == 4 ? LATK(4, false, false) : LATK(5, false, false);
+            else if (lat_planes) rc = multi ? (g.CP == 4 ? LATK(4, true, false) : LATK(5, true, false)) : (g.CP == 4 ? LATK(4, false, false) : LATK(5, false, false));
             else if (multi) rc = g.CP == 4 ? LATK(4, true, true) : LATK(5, true, true);
             else rc = g.CP == 4 ? LATK(4, false, true) : LATK(5, false, true);
 #undef LATK
@@ -1926,6 +1906,12 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                 return 0;
             };
             if (int rc = g.CP == 4 ? go(gram_fused_kernel<RQAE_X_BF16, 4, true, 6>) : go(gram_fused_kernel<RQAE_X_BF16, 5, true, 6>)) return rc;
+        } else if (r3_go) {
+            rqae_r3::Args ar;
+            ar.img = v.wout3_img; ar.maxbits = v.wout_maxbits; ar.bias = v.bias_prefix + (size_t)(levels - 1) * d;
+            ar.planes = reinterpret_cast<const float *>(cvimg); ar.out = q_out + (size_t)t0 * d; ar.n_tokens = nt; ar.tok_pad = tp;
+            ar.d = d; ar.c = c; ar.L = L; ar.levels = levels; ar.cvs = wide ? 16 : g.CP;
+            if (int rc = rqae_r3::launch(ar, ncu, s)) return rc;
         } else if (q_out && wide) {
             RecWideParams pw;
             pw.wout_img = v.wout_img; pw.bias = v.bias_prefix + (size_t)(levels - 1) * d; pw.cvf = reinterpret_cast<const float *>(cvimg);

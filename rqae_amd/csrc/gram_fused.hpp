@@ -112,13 +112,6 @@ __host__ inline long long ftile_count(long long n_tokens, long long G, int stagg
     return G + (n_tokens - 192 * G + 255) / 256;
 }
 
-__device__ __forceinline__ void wave_sync_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 #ifdef RQAE_FUSED_TIMELINE
 #define F_STAMP(i)                                                                                                         \
     do {                                                                                                                   \

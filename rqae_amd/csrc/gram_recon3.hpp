@@ -1,0 +1,399 @@
+// gram_recon3.hpp -- round 4's reconstruction of the matrix-core arm (included by recon3.hip inside its anonymous namespace).
+//
+//   out[tok][e] = sum_l ( W_out[l][e][:] . cv_l[tok][:] + b_out[l][e] )          (rqae/model.py:221,224 as the decode sum, :236-248)
+//
+// What changed against gram_fused_kernel<.., MODE 3> / gram_reconstruct_kernel / gram_recon_wide_kernel:
+//   * operands are TWO fp16 pieces per fp32 value instead of three bf16 pieces: hi = rn16(v), lo = rn16(v - hi) leave a remainder
+//     below 2^-24 |v| (fp16 carries 11 significant bits, bf16 8), so the three products hi*hi + hi*lo + lo*hi reproduce the fp32
+//     product to ~2^-23 where the bf16 form needed six -- HALF the matrix instructions at the same fp32-level accuracy.  fp16's
+//     narrow exponent is met by exact power-of-two scalings: the W_out image is scaled at pack time so that its largest magnitude
+//     sits in [2^14, 2^15) (gram_pack_absmax_kernel leaves the exponent in the block's header), the straight-through values by
+//     2^R3_CV_SHIFT (unit codebook rows: |cv| <= 1 up to one ulp of the projection); the accumulator starts at the scaled bias sum
+//     and is multiplied by the inverse scale once at the end -- powers of two, so no rounding is added;
+//   * v_mfma_f32_32x32x16_f16: a 1-KiB operand fragment feeds 32 x 32 x 16 products (twice what a 16x16x32 fragment feeds), so the
+//     W_out fragments can come from LDS once per 32-token wave at a third of the LDS array's rate, and one accumulator chain needs
+//     no interleaving (MI355X_MICROARCH.md, cycle constants);
+//   * the pieces of a wave's 32 tokens for ALL k-steps stay in registers (B operand: KS x 8 registers), built once per token tile
+//     from the level chain's fp32 planes through the wave's LDS buffer; any depth up to 16 k-steps (256 values) -- C2, C4, C5 and
+//     the released shape at depth <= 64 take the same kernel (the three earlier kernels split these shapes between them);
+//   * every store instruction writes ONE token row of 1 KiB (NT = 8 element tiles per block) or two rows of 512 bytes (NT = 4).
+// One workgroup = 8 waves x 32 tokens (one workgroup per CU, two waves per SIMD), persistent over 256-token tiles.  The W_out
+// image streams L2 -> LDS by LDS-DMA through a 3-slot ring, G element tiles (all k-steps, both pieces) per stage; counted vmcnt
+// waits and one raw barrier per stage, as in gram_fused_kernel.  Tier-2 parity like the rest of the arm.
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int R3_NW = 8;                 // waves per workgroup
+constexpr int R3_TILE = R3_NW * 32;      // tokens per tile
+constexpr int R3_WBUF = 8704;            // bytes of LDS per wave: piece build (32 rows x 272) / transposition (8 x 1056 or 16 x 544)
+constexpr int R3_CV_SHIFT = 10;          // straight-through values are scaled by 2^10 before they are cut into fp16 pieces
+constexpr int R3_BK = 4;                 // k-steps per trip of the piece build through the wave's buffer
+
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// fp32 -> two fp16 pieces, round to nearest: v = hi + lo + r, |r| <= 2^-24 |v| (for |v| inside fp16's normal range; below it the
+// absolute error is at most half a subnormal step, 2^-25).  Values beyond fp16's range are clamped first (inf - inf would be NaN).
+__device__ __forceinline__ void split2(float v, unsigned short &hi, unsigned short &lo)
+{
+    v = v > 60000.0f ? 60000.0f : v < -60000.0f ? -60000.0f : v;      // (a NaN stays a NaN: the reference's NaN rows stay NaN rows)
+    const _Float16 h = (_Float16)v;
+    const float r = v - (float)h;
+    const _Float16 l = (_Float16)r;
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+// k-steps (of 16 values) the reconstruction of `levels` levels runs over, and the instantiated depths
+__host__ __device__ inline int r3_ksteps(int c, int levels) { return (c * levels + 15) / 16; }
+inline int r3_ks_template(int ks)
+{
+    const int cand[] = {2, 3, 4, 8, 13, 16};
+    for (int v : cand)
+        if (ks <= v) return v;
+    return 0;
+}
+// element tiles per ring stage: stages of 16-26 KiB (three of them beside 68 KiB of wave buffers and the bias sums)
+__host__ __device__ constexpr int r3_group(int KS) { return KS <= 3 ? 4 : KS <= 4 ? 2 : 1; }
+__host__ __device__ inline size_t r3_lds_bytes(int d, int KS) { return pad1k((size_t)d * 4) + 3 * (size_t)r3_group(KS) * KS * 2048 + (size_t)R3_NW * R3_WBUF; }
+
+// ------------------------------------------------------------------------------------------------ pack
+// largest |W_out| as float bits (non-negative floats order like unsigned integers)
+__global__ void gram_pack_absmax_kernel(const float *w, size_t n, unsigned *out_bits)
+{
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = __builtin_fabsf(w[i]);
+        m = a > m ? a : m;        // NaN never wins: the image of a NaN weight is NaN whatever the scale
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
+}
+
+// the exact power of two that brings `maxbits` (a float's bits) into [2^14, 2^15): its exponent T (a weight w goes in as w 2^T)
+__host__ __device__ inline int r3_shift_of(unsigned maxbits)
+{
+    const int e = (int)((maxbits >> 23) & 255u);      // max = 1.m x 2^(e - 127); zero / subnormal: no scaling worth doing
+    if (e == 0 || e == 255) return 0;
+    return 14 - (e - 127);
+}
+__device__ __forceinline__ float f32_bits(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float r3_pow2(int t) { return __builtin_bit_cast(float, (unsigned)((t + 127) << 23)); }     // -126 <= t <= 127
+
+// W_out image for v_mfma_f32_32x32x16_f16: fragment (mt, ks, piece) = 1 KiB = the A operand: lane l holds element 32 mt + (l & 31),
+// values k = 16 ks + 8 (l >> 5) + j, j = 0..7; value k = level k / c, component k % c (tight: no padding between levels), zero past
+// L c; every weight scaled by 2^T (T from the header word gram_pack_absmax_kernel left).
+__global__ void gram_pack_wout3_kernel(int d, int c, int L, const float *w_out, const unsigned *maxbits, uint16_t *img, int KS3)
+{
+    const int T = r3_shift_of(*maxbits);
+    const float sc = r3_pow2(T > 100 ? 100 : T < -100 ? -100 : T);
+    const int NMT = d / 32;
+    const size_t total = (size_t)NMT * KS3 * 2 * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t f = i >> 9;
+        const int piece = (int)(f & 1); f >>= 1;
+        const int ks = (int)(f % KS3);
+        const int mt = (int)(f / KS3);
+        const int e = 32 * mt + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+        float v = 0.0f;
+        if (k < L * c) v = w_out[((size_t)(k / c) * d + e) * c + (k % c)] * sc;
+        unsigned short hi, lo;
+        split2(v, hi, lo);
+        img[i] = piece ? lo : hi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel
+struct Rec3Params {
+    const uint16_t *wimg;        // [d / 32][KS3][2][512]
+    const unsigned *maxbits;     // the header word of gram_pack_absmax_kernel (the image's scale)
+    const float *bias;           // bias_prefix[levels - 1][d]
+    const float *cvf;            // fp32 planes [level][tok_pad][cvs]
+    float *out;                  // [n_tokens][d]
+    long long n_tokens, tok_pad;
+    int d, c, levels, KS3;       // KS3: k-steps per element tile in the image (the block's full depth)
+    int cvs;                     // floats per token and level in the planes (c <= cvs)
+};
+
+#ifndef R3_ABL     /* tools builds: timing-only ablations (wrong results): 1 = no matrix instructions, 2 = no global stores, 4 = no W_out DMA */
+#define R3_ABL 0
+#endif
+
+// KS: k-steps resident in registers (>= r3_ksteps(c, levels)).
+// CPF: 4 / 5 = the planes hold exactly CPF floats per token and level (the lean chains) and the NEXT tile's values are fetched into
+// registers before the current tile's last stores are issued -- so no load ever waits behind a tile's stores (loads and stores
+// retire through one in-order counter); 0 = any plane width (p.cvs), values loaded at the tile's start.
+// The W_out stages form ONE stream over all tiles of the workgroup (the stage after a tile's last one is the next tile's first --
+// the same image), so nothing is drained or re-primed at a tile boundary.
+// Output: a PAIR of element tiles (32 tokens x 64 elements) at a time -- the two accumulators go through the wave's LDS buffer with
+// every lane writing (a ds_write_b128 occupies the LDS for its full 1-KiB slot however few lanes are active: the first form of this
+// kernel, with quarter-active writes of eight tiles at once, spent 0.33 of its 0.49 ms there), and leave as 4 token rows x 256
+// bytes per store instruction (5.80 TB/s on the full chip against 6.07 for 1-KiB rows, profiles/r02_store_patterns.txt).
+template <int KS, int CPF>
+__global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
+{
+    constexpr int G = r3_group(KS);                               // element tiles per stage: 4, 2 or 1
+    constexpr int STAGE = G * KS * 2048;
+    constexpr int NPC = G * KS * 2;                               // 1-KiB pieces per stage
+    constexpr int NPB = NPC / R3_NW, NPX = NPC % R3_NW;           // per wave: NPB, one more on waves < NPX
+    constexpr int NSS = G == 4 ? 16 : 8;                          // store instructions per wave in a stage that completes pairs (G = 1: every second stage)
+    constexpr int NS2 = G == 4 ? 32 : G == 2 ? 16 : 8;            // ... in two consecutive stages
+    constexpr bool PREF = CPF != 0;
+    constexpr int LM = PREF ? (16 * KS) / CPF : 1;                // levels a prefetching instantiation can hold (c == CPF)
+    constexpr int NL = PREF ? (32 * CPF + 63) / 64 : 1;           // plane floats per lane and level (a wave's 32 tokens x CPF, lane-contiguous)
+    constexpr int TRS = 272;                                      // transposition rows: 64 elements x 4 bytes + 16
+    static_assert(32 * TRS <= R3_WBUF, "the pair's rows fit the wave's buffer");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned bias_bytes = (unsigned)pad1k((size_t)p.d * 4);
+    const unsigned off_ring = bias_bytes;
+    char *wbuf = smem + off_ring + 3 * STAGE + wave * R3_WBUF;
+    const int Tsh = r3_shift_of(*p.maxbits);
+    const int Tc = Tsh > 100 ? 100 : Tsh < -100 ? -100 : Tsh;
+    const float bsc = r3_pow2(Tc) * (float)(1 << R3_CV_SHIFT);      // accumulators live at scale 2^(T + shift) ...
+    const float isc = 1.0f / bsc;                                    // ... an exact power of two either way
+    const int nstg = p.d / (32 * G);                                // stages per tile (d % 128 == 0: whole stages, whole pairs)
+    const int kval = p.c * p.levels;                                // values in use
+    const long long ntile = (p.n_tokens + R3_TILE - 1) / R3_TILE;
+    if ((long long)blockIdx.x >= ntile) return;
+    // bias sums, scaled, once per workgroup
+    for (int i = tid; i < (int)(bias_bytes >> 2); i += R3_NW * 64) reinterpret_cast<float *>(smem)[i] = i < p.d ? p.bias[i] * bsc : 0.0f;
+    auto issue = [&](int s_in, int slot) {
+        if (R3_ABL & 4) return;
+        const int s = s_in < nstg ? s_in : s_in - nstg;            // the stream wraps round: the next tile starts with the same image
+        const int mt0 = s * G;
+        for (int q = wave; q < NPC; q += R3_NW) {
+            const int gi = q / (KS * 2), rem = q - gi * (KS * 2);
+            int ks = rem >> 1;
+            ks = ks < p.KS3 ? ks : p.KS3 - 1;                      // k-steps past the image's depth (KS > KS3): any fragment -- their token pieces are zero
+            dma_piece(uniform_ptr(p.wimg + (((size_t)(mt0 + gi) * p.KS3 + ks) * 2 + (rem & 1)) * 512), lds0 + off_ring + slot * STAGE + q * 1024, lane16);
+        }
+    };
+    // the wave's rows of a tile: first row, how many exist (rows past the batch re-read the last one; never stored)
+    auto rows_of = [&](long long tile, long long &trow0, int &rows_ok) {
+        const long long tile0 = tile * R3_TILE;
+        const long long tile_end = tile0 + R3_TILE < p.n_tokens ? tile0 + R3_TILE : p.n_tokens;
+        const long long tw0 = tile0 + (long long)wave * 32;
+        const bool act = tw0 < tile_end;
+        rows_ok = act ? (int)(tile_end - tw0 < 32 ? tile_end - tw0 : 32) : 1;
+        trow0 = act ? tw0 : tile_end - 1;
+    };
+    // PREF: the raw values of a tile, lane-contiguous per level (idx = it 64 + lane over the wave's 32 x CPF floats)
+    float raw[LM * NL];
+    auto load_raw = [&](long long tile) {
+        if constexpr (PREF) {
+            long long trow0; int rows_ok;
+            rows_of(tile, trow0, rows_ok);
+            static_for<0, LM>([&](auto l_c) {
+                constexpr int l = decltype(l_c)::value;
+                if (l < p.levels) {
+                    const float *pl = p.cvf + ((size_t)l * p.tok_pad + trow0) * CPF;
+#pragma unroll
+                    for (int it = 0; it < NL; ++it) {
+                        const int idx = it * 64 + lane;
+                        const int tk = idx / CPF, comp = idx - tk * CPF;
+                        const int tsrc = tk < rows_ok ? tk : rows_ok - 1;
+                        raw[l * NL + it] = idx < 32 * CPF ? pl[tsrc * CPF + comp] : 0.0f;
+                    }
+                }
+            });
+        }
+    };
+    load_raw(blockIdx.x);
+    __syncthreads();
+    issue(0, 0);
+    issue(1, 1);
+    int slot = 0;
+    int sdone = 0;                // stages done so far (saturating at 2): the first two of the kernel have fewer stores behind them
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long long tile0 = tile * R3_TILE;
+        const long long tile_end = tile0 + R3_TILE < p.n_tokens ? tile0 + R3_TILE : p.n_tokens;
+        const long long tw0 = tile0 + (long long)wave * 32;
+        const bool active = tw0 < tile_end;
+        const bool fullw = tw0 + 32 <= tile_end;
+        // ---- this wave's token pieces (B operands), R3_BK k-steps per trip through the wave's buffer: rows of 32 BK hi + 32 BK lo bytes
+        u32x4 Ahi[KS], Alo[KS];
+        {
+            constexpr int VT = 16 * R3_BK;                          // values per trip
+            constexpr int HB = 2 * VT;                              // bytes of a row's hi pieces; the lo pieces follow
+            constexpr int RS = 2 * HB + 16;                         // row stride: 16 bytes x an odd number (conflict-free b128 reads)
+            static_assert(32 * RS <= R3_WBUF, "a trip's rows fit the wave's buffer");
+            long long trow0; int rows_ok;
+            rows_of(tile, trow0, rows_ok);
+            static_for<0, (KS + R3_BK - 1) / R3_BK>([&](auto t_c) {
+                constexpr int TR = decltype(t_c)::value;
+                const int k0 = VT * TR;                             // first value of this trip
+                // zero the trip's rows first where values past the depth in use fall into it (stale bytes must not reach an MFMA)
+                if (k0 + VT > kval) {
+#pragma unroll
+                    for (int i = 0; i < (32 * RS / 16 + 63) / 64; ++i) {
+                        const int o = (i * 64 + lane) * 16;
+                        if (o < 32 * RS) *reinterpret_cast<u32x4 *>(wbuf + o) = u32x4{0u, 0u, 0u, 0u};
+                    }
+                    wave_sync_lds();
+                }
+                auto put = [&](float v, int tk, int k) {
+                    unsigned short hi, lo;
+                    split2(v * (float)(1 << R3_CV_SHIFT), hi, lo);
+                    *reinterpret_cast<unsigned short *>(wbuf + tk * RS + 2 * k) = hi;
+                    *reinterpret_cast<unsigned short *>(wbuf + tk * RS + HB + 2 * k) = lo;
+                };
+                if constexpr (PREF) {
+                    static_for<0, LM>([&](auto l_c) {
+                        constexpr int l = decltype(l_c)::value;
+                        if (l < p.levels) {
+#pragma unroll
+                            for (int it = 0; it < NL; ++it) {
+                                const int idx = it * 64 + lane;
+                                const int tk = idx / CPF, comp = idx - tk * CPF;
+                                const int k = l * p.c + comp - k0;
+                                if (idx < 32 * CPF && comp < p.c && k >= 0 && k < VT) put(raw[l * NL + it], tk, k);
+                            }
+                        }
+                    });
+                } else {
+                    const int CVS = p.cvs;
+                    const int l_lo = k0 / p.c, l_hi = (k0 + VT - 1) / p.c;  // levels with a value in [k0, k0 + VT)
+                    for (int l = l_lo; l <= l_hi && l < p.levels; ++l) {
+                        const float *pl = p.cvf + ((size_t)l * p.tok_pad + trow0) * CVS;
+                        for (int idx = lane; idx < 32 * CVS; idx += 64) {
+                            const int tk = idx / CVS;
+                            const int comp = idx - tk * CVS;
+                            const int k = l * p.c + comp - k0;
+                            if (comp < p.c && k >= 0 && k < VT) put(pl[(tk < rows_ok ? tk : rows_ok - 1) * CVS + comp], tk, k);
+                        }
+                    }
+                }
+                wave_sync_lds();
+#pragma unroll
+                for (int kl = 0; kl < R3_BK; ++kl)
+                    if (R3_BK * TR + kl < KS) {
+                        Ahi[R3_BK * TR + kl] = *reinterpret_cast<const u32x4 *>(wbuf + r * RS + (16 * kl + 8 * h) * 2);
+                        Alo[R3_BK * TR + kl] = *reinterpret_cast<const u32x4 *>(wbuf + r * RS + HB + (16 * kl + 8 * h) * 2);
+                    }
+                wave_sync_lds();
+            });
+        }
+        float *orow = p.out + (size_t)tw0 * p.d;
+        // one element tile: 3 KS matrix instructions on one accumulator that starts at the scaled bias sum; back to scale 1 at the end
+        auto tile_mm = [&](const char *wb, int gi, int mt_abs) -> f32x16 {
+            f32x16 a;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {       // lane (token r, half h) holds elements 32 mt + 8 i + 4 h + 0..3
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(smem + ((size_t)mt_abs * 32 + 8 * i + 4 * h) * 4);
+                a[4 * i] = b[0]; a[4 * i + 1] = b[1]; a[4 * i + 2] = b[2]; a[4 * i + 3] = b[3];
+            }
+            u32x4 fh[KS], fl[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                fh[ks] = *reinterpret_cast<const u32x4 *>(wb + ((gi * KS + ks) * 2) * 1024);
+                fl[ks] = *reinterpret_cast<const u32x4 *>(wb + ((gi * KS + ks) * 2 + 1) * 1024);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (R3_ABL & 1) {
+                    a[0] += f32_bits(fh[ks][0] ^ Ahi[ks][0] ^ fl[ks][1] ^ Alo[ks][1]);
+                } else {
+                    a = mfma32(fh[ks], Ahi[ks], a);
+                    a = mfma32(fh[ks], Alo[ks], a);
+                    a = mfma32(fl[ks], Ahi[ks], a);
+                }
+            }
+            return a * isc;
+        };
+        // "all reads, then all MFMAs" of one element tile put in order: the bias reads and two k-steps' fragments ahead, then a k-step's
+        // fragments behind each k-step's three matrix instructions
+        auto tile_order = [&]() {
+            if (!(R3_ABL & 1)) {
+                constexpr int PFK = KS < 2 ? KS : 2;
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * PFK, 0);
+#pragma unroll
+                for (int ks = 0; ks < KS - PFK; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * PFK, 0);
+            }
+        };
+        // a finished pair of element tiles (elements el0 .. el0 + 63 of the wave's 32 tokens): every lane writes its token's values,
+        // then 8 x (4 rows x 256 bytes) come back and leave with non-temporal stores
+        auto pair_out = [&](const f32x16 &a0, const f32x16 &a1, int el0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4 *>(wbuf + r * TRS + (8 * i + 4 * h) * 4) = f32x4{a0[4 * i], a0[4 * i + 1], a0[4 * i + 2], a0[4 * i + 3]};
+                *reinterpret_cast<f32x4 *>(wbuf + r * TRS + (32 + 8 * i + 4 * h) * 4) = f32x4{a1[4 * i], a1[4 * i + 1], a1[4 * i + 2], a1[4 * i + 3]};
+            }
+            wave_sync_lds();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 4 * i + (lane >> 4);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(wbuf + row * TRS + (lane & 15) * 16);
+                if ((R3_ABL & 2) ? p.n_tokens < 0 : (fullw || tw0 + row < tile_end))
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(orow + (size_t)row * p.d + el0 + (lane & 15) * 4));
+            }
+            wave_sync_lds();
+        };
+        f32x16 acc_even;          // G == 1: the first tile of a pair waits here for the second (the next stage)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_even[i] = 0.0f;
+        for (int s0 = 0; s0 < nstg; s0 += (G == 1 ? 2 : 1)) {
+            static_for<0, (G == 1 ? 2 : 1)>([&](auto u_c) {
+                constexpr int U = decltype(u_c)::value;
+                const int s = s0 + U;
+                // This stage landed when only the pieces issued one stage ago are younger -- and the stores of the two stages between its
+                // issue and now (none before the kernel's first stage, one stage's worth before its second).  (The values prefetched
+                // for the next tile lie there too at a tile boundary; not counting them waits for a few operations more than needed,
+                // never fewer.)
+                constexpr int ST1 = G == 1 ? (U == 0 ? NSS : 0) : NSS;      // stores of the stage before this one
+                if (!fullw) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ragged wave: its store count is not static
+                } else if (wave < NPX) {
+                    if (sdone >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + NS2) : "memory");
+                    else if (sdone == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + ST1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1) : "memory");
+                } else {
+                    if (sdone >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NS2) : "memory");
+                    else if (sdone == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + ST1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB) : "memory");
+                }
+                __builtin_amdgcn_s_barrier();      // every wave's pieces of this stage landed; every wave has left the stage before
+                issue(s + 2, slot == 0 ? 2 : slot - 1);      // slot (s + 2) % 3 was read last in the stage before
+                const char *wb = smem + off_ring + slot * STAGE + lane * 16;
+                if (active) {
+                    if constexpr (G == 1) {
+                        const f32x16 a = tile_mm(wb, 0, s);
+                        tile_order();
+                        if constexpr (U == 0) acc_even = a;
+                        else {
+                            // (the next tile's values before the tile's last stores: see CPF)
+                            if (PREF && s == nstg - 1 && tile + gridDim.x < ntile) load_raw(tile + gridDim.x);
+                            pair_out(acc_even, a, (s - 1) * 32);
+                        }
+                    } else {
+#pragma unroll
+                        for (int pr = 0; pr < G / 2; ++pr) {
+                            const f32x16 a0 = tile_mm(wb, 2 * pr, s * G + 2 * pr);
+                            tile_order();
+                            const f32x16 a1 = tile_mm(wb, 2 * pr + 1, s * G + 2 * pr + 1);
+                            tile_order();
+                            if (PREF && pr == G / 2 - 1 && s == nstg - 1 && tile + gridDim.x < ntile) load_raw(tile + gridDim.x);
+                            pair_out(a0, a1, (s * G + 2 * pr) * 32);
+                        }
+                    }
+                }
+                slot = slot == 2 ? 0 : slot + 1;
+                sdone = sdone < 2 ? sdone + 1 : 2;
+            });
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stages issued past the last tile must have landed before the workgroup's LDS is handed on
+}

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import json
 import math
+import operator
 import os
 from itertools import product
 
@@ -28,6 +29,7 @@ import torch.nn.functional as F
 from . import _native
 
 _FSQ_METHODS = ("fsq", "round_fsq")
+_TENSOR_VERSION = operator.attrgetter("_version")
 
 
 def _fsq_grid(codebook_dim: int, codebook_size: int, unit_rows: bool) -> torch.Tensor:
@@ -130,6 +132,8 @@ class RQAE(nn.Module):
         self._gram = None
         self.__dict__.pop("_gram_scaled", None)
         self.__dict__.pop("_gram_free", None)
+        self.__dict__.pop("_param_list", None)   # the key's snapshots restart with the caches (a stale snapshot
+        self.__dict__.pop("_key_state", None)    # made each of the next 16 calls find a "changed" slice and repack)
         self._gram_ws = None
         self._drop_metadata_cache()
         return super()._apply(fn, *args, **kwargs)
@@ -139,6 +143,8 @@ class RQAE(nn.Module):
         self._gram = None
         self.__dict__.pop("_gram_scaled", None)
         self.__dict__.pop("_gram_free", None)
+        self.__dict__.pop("_param_list", None)
+        self.__dict__.pop("_key_state", None)
         self._drop_metadata_cache()
         return super().load_state_dict(*args, **kwargs)
 
@@ -165,20 +171,24 @@ class RQAE(nn.Module):
     def _dims(self):
         return (self._dim, self.codebook_dim, self.codebook.shape[1], self.num_quantizers)
 
-    _KEY_WALK_ALL = 512      # parameter tensors up to which every call checks every one of them
-    _KEY_SLICES = 16         # beyond that, in eval mode: one sixteenth of the list per call, round robin
+    _KEY_WALK_ALL = 512      # parameter tensors up to which every call also re-reads every storage pointer
+    _KEY_SLICES = 16         # beyond that: one sixteenth of the POINTERS per call, round robin (see _weights_key)
+    key_check = "full"       # "full" (default): every tensor's version counter at every call; "sliced": opt-in, see _weights_key
 
     def _weights_key(self):
-        """Fingerprint of the parameters the packed blocks were built from: device, mode, and the storage pointers and version
-        counters of the parameter tensors (the reference reads the weights live at every call, rqae/model.py:199-230, so an
-        in-place edit of any level must be seen).
+        """Fingerprint of the parameters the packed blocks were built from: device, mode, the version counters and the storage
+        pointers of the parameter tensors (the reference reads the weights live at every call, rqae/model.py:199-230, so an
+        in-place edit of any level must be seen by the NEXT call).
 
-        Cost: the walk is a Python loop, 0.7 ms for the 4097 tensors of the pretrained shape (measured; 0.17 us per tensor) --
-        a fifth of a 512-token hook call.  So: up to 512 tensors (every BASELINE config), or while ``self.training``, EVERY
-        tensor is checked at EVERY call.  A larger module in eval mode checks the codebook and one sixteenth of the list per
-        call, round robin: ``load_state_dict`` / ``.to()`` / ``_apply`` drop the cache at once as before, an in-place edit of one
-        level's weights in eval mode is seen within 16 calls -- call ``invalidate_packed()`` to see it at the next one.  A
-        ``.data`` write that keeps the storage (``p.data.copy_``) bumps no counter: ``invalidate_packed()`` as well."""
+        Default (``key_check = "full"``): the version counter of EVERY tensor is read at EVERY call -- one C-level pass
+        (``sum(map(attrgetter("_version"), ...))``: 0.29 ms for the 4097 tensors of the released shape, 0.6 us for C2's 33) -- so
+        an in-place edit (``p.zero_()``, ``p.mul_()``, ``p.copy_()`` under ``no_grad``) is never missed.  Storage pointers change
+        only when a parameter is re-bound (``.to()`` / ``_apply`` / ``load_state_dict`` drop the caches themselves; ``p.data = t`` is
+        the rest): up to 512 tensors every pointer is re-read at every call as well, larger modules re-read a sixteenth of the
+        pointers per call, round robin.  ``key_check = "sliced"`` (explicit opt-in, for the 1024-level module in a latency-critical
+        loop whose weights are frozen): versions too are re-read a sixteenth per call -- an in-place edit is then seen within 16
+        calls; ``invalidate_packed()`` forces it.  A write through ``.data`` that keeps the storage (``p.data.zero_()``) bumps no
+        counter in either mode: call ``invalidate_packed()`` after it."""
         plist = self.__dict__.get("_param_list")
         if plist is None or len(plist) != 4 * len(self.layers) + 1:
             plist = [self.codebook]
@@ -187,15 +197,14 @@ class RQAE(nn.Module):
             self.__dict__["_param_list"] = plist
             self.__dict__["_key_state"] = None
         n = len(plist)
-        if n <= self._KEY_WALK_ALL or self.training:
-            ver = 0
+        if n <= self._KEY_WALK_ALL:
             ptr = 0
             for t in plist:
-                ver += t._version
                 ptr ^= t.data_ptr()
-            return (self.codebook.device, self.training, ptr, ver, n)
-        # large module, eval mode: per-tensor snapshot, one slice re-read per call; the key carries a generation number that moves
-        # whenever a re-read tensor differs from its snapshot
+            return (self.codebook.device, self.training, ptr, sum(map(_TENSOR_VERSION, plist)), n)
+        sliced = self.key_check == "sliced" and not self.training
+        # large module: per-tensor snapshot of (version, pointer), one slice re-read per call; the key carries a generation number
+        # that moves whenever a re-read tensor differs from its snapshot -- and, by default, the sum of ALL version counters
         st = self.__dict__.get("_key_state")
         if st is None or len(st["snap"]) != n:
             st = {"snap": [(t._version, t.data_ptr()) for t in plist], "gen": 0, "turn": 0}
@@ -212,7 +221,7 @@ class RQAE(nn.Module):
             st["turn"] = (k + 1) % self._KEY_SLICES
             if changed:
                 st["gen"] += 1
-        return (self.codebook.device, self.training, st["gen"], n)
+        return (self.codebook.device, self.training, st["gen"], -1 if sliced else sum(map(_TENSOR_VERSION, plist)), n)
 
     def invalidate_packed(self):
         """Drop the packed parameter blocks (call after a ``.data`` write that the version counters cannot see)."""

@@ -585,6 +585,26 @@ def test_gram_sees_weight_edits():
             assert np.array_equal(after, oracle.forward(x, w2)[1])
 
 
+def test_weight_edits_are_seen_at_once_on_the_released_1024_level_module():
+    """the 4097-tensor module (rqae/model.py:18-24) reads every version counter at every call by default --
+    an in-place edit of ONE level (an ablation: a level's lin_out zeroed) changes the very next forward, on either arm."""
+    cfg = dict(dim=2304, codebook_dim=4, codebook_size=5, num_quantizers=1024)
+    w = synth.weights(21, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    x = synth.activations(14, 256, cfg["dim"])
+    m = make_model(cfg, w, "auto")
+    assert m.key_check == "full"
+    _, before, _ = run(m, x, torch.float32, max_layers=24)
+    _, again, _ = run(m, x, torch.float32, max_layers=24)
+    assert np.array_equal(before, again)
+    with torch.no_grad():
+        m.layers[7][0].weight.mul_(-1.0)
+    _, after, _ = run(m, x, torch.float32, max_layers=24)       # the NEXT call
+    assert np.array_equal(after[:, :7], before[:, :7]) and not np.array_equal(after[:, 7:], before[:, 7:])
+    w2 = {k: v.copy() for k, v in w.items()}
+    w2["w_in"][7] *= -1.0
+    assert np.array_equal(after, oracle.forward(x, w2, max_layers=24)[1])
+
+
 def test_gram_captures_into_a_hip_graph():
     cfg = synth.CONFIGS["C2"]
     w = synth.weights(3, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])

@@ -123,12 +123,27 @@ def test_weights_key_sees_every_parameter():
     k1 = m._weights_key()
     m.layers[2][1].bias.data = m.layers[2][1].bias.data.clone()   # new storage
     assert m._weights_key() != k1
-    # a module with more than 512 parameter tensors in eval mode re-reads a sixteenth of them per call (the full
-    # walk cost 0.7 ms per call at the pretrained shape): an in-place edit is seen within 16 calls, at once after
-    # invalidate_packed(), and at every call while training
+    # a module with more than 512 parameter tensors (the released 4097-tensor shape): by default EVERY version counter is read at
+    # EVERY call (the reference reads weights live, rqae/model.py:208-221) -- an in-place edit of any level
+    # changes the very next key, exactly once; only the storage POINTERS are re-read a sixteenth per call
     big = RQAE(dim=8, codebook_dim=2, codebook_size=2, num_quantizers=200).eval()
     k0 = big._weights_key()
     assert big._weights_key() == k0
+    with torch.no_grad():
+        big.layers[137][1].weight.add_(1.0)
+    keys = [big._weights_key() for _ in range(20)]
+    assert keys[0] != k0 and len(set(keys)) <= 2 and keys[-1] == keys[-2]      # seen at once; settles (no flapping)
+    # re-binding a parameter's storage: seen within 16 calls by the pointer slices
+    kk = big._weights_key()
+    big.layers[90][0].bias.data = big.layers[90][0].bias.data.clone()
+    assert any(big._weights_key() != kk for _ in range(16))
+    # load_state_dict restarts the snapshots: ONE new key, not sixteen
+    big.load_state_dict(big.state_dict())
+    keys = [big._weights_key() for _ in range(18)]
+    assert len(set(keys)) == 1
+    # the explicit opt-in: versions too are sampled -- an edit is seen within 16 calls, at once after invalidate_packed()
+    big.key_check = "sliced"
+    k0 = big._weights_key()
     with torch.no_grad():
         big.layers[137][1].weight.add_(1.0)
     keys = [big._weights_key() for _ in range(16)]

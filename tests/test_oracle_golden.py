@@ -176,3 +176,16 @@ def test_tables_against_reference_capture(tag):
     assert (np.abs(mine - ref.astype(np.float64)) <= 0.5 * ulp + 2e-6).all()        # fp16 rounding + fp32 product
     assert (mine.astype(np.float16).view(np.uint16) == ref.view(np.uint16)).mean() > 0.999
     assert np.abs(oracle.layer_norms(w) / g[tag + "_layer_norms"] - 1).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["fwd_c1", "fwd_c2", "fwd_c2_max3", "fwd_c5", "fwd_p", "fwd_ragged"])
+def test_torch_ops_restatement_matches_reference(name):
+    """oracle/torch_ops.py (bench.py's cpu_baseline of kind "reference-ops": the reference's operator sequence) against
+    the reference captures: the same ATen operators on the same values, so codes AND reconstruction rows are the capture's bits."""
+    from oracle import torch_ops
+
+    g = load_golden(name)
+    cfg, w, x = case_inputs(g)
+    q, idx = torch_ops.forward(x, w, max_layers=g["meta"]["max_layers"])
+    assert np.array_equal(idx, g["codes"].astype(np.int64))
+    assert np.array_equal(q[g["rows"]], g["q_rows"])

@@ -64,7 +64,7 @@ GRAM_MFMA_FLOPS_PER_TOKEN = 2 * D * 48 * 3 + L * 2 * K * 32 + 2 * D * 256
 
 PROFILE_ROUND = "r03"     # profiles/<round>_traffic.json, <round>_pmc_summary.json: the committed counter passes of this round
 
-KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "gram_wide.hpp", "gram_recon3.hpp", "gram_small.hpp", "recon3.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
+KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "gram_wide.hpp", "gram_recon3.hpp", "gram_small.hpp", "gram_pieces.hpp", "recon3.hip", "gram_proj3.hpp", "proj3.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
 
 
 def sources_hash():

@@ -33,6 +33,7 @@
 
 #include "../../include/rqae_hip.h"
 #include "recon3.h"
+#include "proj3.h"
 
 extern __attribute__((visibility("hidden"))) __thread char rqae_g_err[512];   // __thread, not thread_local: no TLS init wrapper (a hidden weak _ZTH call crashes)
 
@@ -108,7 +109,7 @@ __host__ __device__ inline int nks_recon(const Geom &g, int levels)
 }
 
 struct GLayout {
-    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, wout3_img, total;
+    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, wout3_img, win3_img, total;
 };
 
 GLayout make_glayout(const Geom &g)
@@ -124,6 +125,7 @@ GLayout make_glayout(const Geom &g)
     lo.wout_img = off;    off += al256((size_t)g.NET * g.NKSC * 1024);
     lo.bias_prefix = off; off += al256(sizeof(float) * (size_t)g.L * g.d + 1024);                        // + 1 KiB: the fused kernel stages a row in whole 1-KiB pieces
     lo.wout3_img = off;   off += al256(rqae_r3::image_bytes(g.d, g.c, g.L));                              // fp16 two-piece W_out image (gram_recon3.hpp)
+    lo.win3_img = off;    off += al256(rqae_p3::image_bytes(g.d, g.NOG));                                   // fp16 two-piece W_in image (gram_proj3.hpp)
     lo.total = off;
     return lo;
 }
@@ -133,7 +135,8 @@ struct GHeader {
     int lattice_n;            // n >= 2: the shared codebook is the FSQ lattice {linspace(-1, 1, n)}^c (gram_pack_lattice_kernel); else 0
     int lattice_miss[2];      // scratch of that check: rows that are not the unit-length lattice row / not the plain lattice row
     unsigned wout_maxbits;    // bits of max |W_out| (gram_pack_absmax_kernel): fixes the power-of-two scale of the fp16 image
-    int pad[54];
+    unsigned win_maxbits;     // the same for W_in (x in_scale)
+    int pad[53];
 };
 static_assert(sizeof(GHeader) == 256, "header");
 
@@ -1239,7 +1242,8 @@ constexpr int B_NW = 8;
 struct Tuning {
     int c_tt;            // reconstruct kernel: 16-token tiles per wave (2: 8 waves per workgroup, 1: 16 waves)
     long long chunk;     // tokens per pass
-    int proj;            // projection kernel: 3 = phase A of the fused kernel (default for 2-byte x), 2 = pipelined register form, 1 = first form
+    int proj;            // projection kernel: 4 = gram_proj3_kernel (fp16 two-piece W_in, 32x32x16, every output tile in one launch: the default up to
+                         // 256 outputs), 3 = phase A of the fused kernel (2-byte x), 2 = pipelined register form, 1 = first form
     int recon;           // reconstruction kernel: 3 = gram_recon3_kernel (fp16 two-piece operands, 32x32x16, 1-KiB store rows: the default wherever
                          // the level chain hands over fp32 planes), 2 = phase C of the fused kernel (one level group), 1 = weights-stationary form
     long long pipe_chunk; // tokens per pass of the pipelined schedule (0: never pipeline)
@@ -1258,7 +1262,7 @@ Tuning default_tuning()
     Tuning v;
     v.chunk = GRAM_CHUNK;
     v.c_tt = 2;
-    v.proj = 3;
+    v.proj = 4;
     v.recon = 3;
     v.fused = 0;
     v.pipe_chunk = 0;       // off: measured slower (profiles/r02_pipeline_trace.txt): the kernels are bound per CU, not by HBM
@@ -1268,7 +1272,7 @@ Tuning default_tuning()
     v.stagger = 0;
 #ifdef RQAE_GRAM_TOOLS
     static const Tuning env = [v]() mutable {
-        if (const char *e = getenv("RQAE_GRAM_PROJ")) { const int a = atoi(e); v.proj = a >= 1 && a <= 3 ? a : 3; }
+        if (const char *e = getenv("RQAE_GRAM_PROJ")) { const int a = atoi(e); v.proj = a >= 1 && a <= 4 ? a : 4; }
         if (const char *e = getenv("RQAE_GRAM_RECON")) { const int a = atoi(e); v.recon = a >= 1 && a <= 3 ? a : 3; }
         if (const char *e = getenv("RQAE_GRAM_FUSED")) v.fused = atoi(e) != 0;
         if (const char *e = getenv("RQAE_GRAM_PIPE")) { const long long c = atoll(e); v.pipe_chunk = c <= 0 ? 0 : ((c + 255) & ~255LL); }
@@ -1293,7 +1297,7 @@ int make_tuning(const rqae_hip_gram_options *o, Tuning &t)
     if (o->size != (int32_t)sizeof(rqae_hip_gram_options)) return gfail("gram options: size %d, this library expects %d", (int)o->size, (int)sizeof(rqae_hip_gram_options));
     if (o->fused >= 0) t.fused = o->fused != 0;
     if (o->pipe_chunk >= 0) t.pipe_chunk = o->pipe_chunk == 0 ? 0 : ((o->pipe_chunk + 255) & ~255LL);
-    if (o->proj > 3 || o->recon > 3 || o->lean_levels > 5) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
+    if (o->proj > 4 || o->recon > 3 || o->lean_levels > 5) return gfail("gram options: proj %d / recon %d / lean_levels %d out of range", o->proj, o->recon, o->lean_levels);
     if (o->proj >= 1) t.proj = o->proj;
     if (o->recon >= 1) t.recon = o->recon;
     // 0..3 name a scan kernel; 4 = lattice form with the scan kernel behind it; 5 = lattice form alone (the caller has asked
@@ -1318,9 +1322,9 @@ int device_cus()
 
 struct GView {
     Geom g;
-    const uint16_t *win_img, *cb_img, *wout_img, *wout3_img;
+    const uint16_t *win_img, *cb_img, *wout_img, *wout3_img, *win3_img;
     const float *kconst, *gneg, *cb_f32, *bias_prefix;
-    const unsigned *wout_maxbits;
+    const unsigned *wout_maxbits, *win_maxbits;
 };
 
 // the header lives on the device; the caller passes (d, c, K, L) again and the geometry is recomputed
@@ -1339,6 +1343,8 @@ GView gview(const void *packed, int d, int c, int K, int L, int shared_cb)
     v.bias_prefix = reinterpret_cast<const float *>(b + lo.bias_prefix);
     v.wout3_img = reinterpret_cast<const uint16_t *>(b + lo.wout3_img);
     v.wout_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, wout_maxbits));
+    v.win3_img = reinterpret_cast<const uint16_t *>(b + lo.win3_img);
+    v.win_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, win_maxbits));
     return v;
 }
 
@@ -1501,6 +1507,8 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
     G_TRY(hipGetLastError());
     // the fp16 two-piece image of W_out (gram_recon3.hpp): its power-of-two scale follows from max |W_out|, found on the device
     if (int rc = rqae_r3::pack(b + lo.wout3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, wout_maxbits)), d, c, L, w_out, s)) return rc;
+    // ... and of W_in (gram_proj3.hpp), in_scale folded in like the bf16 image's
+    if (int rc = rqae_p3::pack(b + lo.win3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, win_maxbits)), d, c, L, g.CP, g.GL, g.GP, g.NOG, w_in, in_scale, s)) return rc;
     return 0;
 }
 
@@ -1565,7 +1573,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     unsigned *cvimg2 = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(cvimg) + al256(cv_row_bytes(g, levels) * tp));
     float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg2) + al256(cv_row_bytes(g, levels) * tp));
 
-    if (inv_rms && !(tuning().proj == 3 && g.CP <= 5 && x_dtype != RQAE_X_F32 && d % 64 == 0))
+    const bool p3_go = tuning().proj == 4 && rqae_p3::supported(d, g.NOG, x_dtype, inv_rms != nullptr);
+    if (inv_rms && !p3_go && !(tuning().proj >= 3 && g.CP <= 5 && x_dtype != RQAE_X_F32 && d % 64 == 0))
         return gfail("encode_gram_gemma: the folded norm is served for bf16 / fp16 hidden states with d %% 64 == 0 (d=%d, x_dtype=%d)", d, x_dtype);
     if (!inv_rms && tuning().fused && x_dtype != RQAE_X_F32 && fused_shape_ok(g, levels)) {
         FusedParams pf;
@@ -1633,7 +1642,12 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pa.win_img = v.win_img; pa.P = P; pa.dump = dump; pa.n_tokens = nt; pa.tok_pad = tp; pa.d = d; pa.NOG = g.NOG; pa.KSA = g.KSA;
         // the LDS-DMA projection covers 3 (c = 5) or 2 (c <= 4) output groups per workgroup; deeper shapes launch ny workgroups per token
         // tile, placed on one XCD so that the tile's x is read from HBM once (RQAE_GRAM_PROJ=2: the register-pipelined kernel instead)
-        if (tuning().proj == 3 && g.CP <= 5 && x_dtype != RQAE_X_F32 && d % 64 == 0) {
+        if (p3_go) {
+            rqae_p3::Args ap;
+            ap.img = v.win3_img; ap.maxbits = v.win_maxbits; ap.x = pa.x; ap.P = P; ap.inv_rms = inv_rms ? inv_rms + t0 : nullptr; ap.eps = eps;
+            ap.n_tokens = nt; ap.tok_pad = tp; ap.d = d; ap.nog = g.NOG; ap.x_dtype = x_dtype;
+            if (int rc = rqae_p3::launch(ap, ncu, s)) return rc;
+        } else if (tuning().proj >= 3 && g.CP <= 5 && x_dtype != RQAE_X_F32 && d % 64 == 0) {
             FusedParams pf;
             memset(&pf, 0, sizeof(pf));
             pf.x = pa.x; pf.win_img = v.win_img; pf.P = P; pf.tok_pad = tp; pf.n_tokens = nt; pf.d = d; pf.K = K; pf.KTP = g.KTP; pf.c = c;

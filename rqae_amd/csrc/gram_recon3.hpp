@@ -21,31 +21,11 @@
 // image streams L2 -> LDS by LDS-DMA through a 3-slot ring, G element tiles (all k-steps, both pieces) per stage; counted vmcnt
 // waits and one raw barrier per stage, as in gram_fused_kernel.  Tier-2 parity like the rest of the arm.
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int R3_NW = 8;                 // waves per workgroup
 constexpr int R3_TILE = R3_NW * 32;      // tokens per tile
-constexpr int R3_WBUF = 8704;            // bytes of LDS per wave: piece build (32 rows x 272) / transposition (8 x 1056 or 16 x 544)
+constexpr int R3_WBUF = 4608;            // bytes of LDS per wave: piece build / transposition of one element tile (32 rows x 144)
 constexpr int R3_CV_SHIFT = 10;          // straight-through values are scaled by 2^10 before they are cut into fp16 pieces
-constexpr int R3_BK = 4;                 // k-steps per trip of the piece build through the wave's buffer
-
-__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-// fp32 -> two fp16 pieces, round to nearest: v = hi + lo + r, |r| <= 2^-24 |v| (for |v| inside fp16's normal range; below it the
-// absolute error is at most half a subnormal step, 2^-25).  Values beyond fp16's range are clamped first (inf - inf would be NaN).
-__device__ __forceinline__ void split2(float v, unsigned short &hi, unsigned short &lo)
-{
-    v = v > 60000.0f ? 60000.0f : v < -60000.0f ? -60000.0f : v;      // (a NaN stays a NaN: the reference's NaN rows stay NaN rows)
-    const _Float16 h = (_Float16)v;
-    const float r = v - (float)h;
-    const _Float16 l = (_Float16)r;
-    hi = __builtin_bit_cast(unsigned short, h);
-    lo = __builtin_bit_cast(unsigned short, l);
-}
+constexpr int R3_BK = 2;                 // k-steps per trip of the piece build through the wave's buffer
 
 // k-steps (of 16 values) the reconstruction of `levels` levels runs over, and the instantiated depths
 __host__ __device__ inline int r3_ksteps(int c, int levels) { return (c * levels + 15) / 16; }
@@ -56,8 +36,8 @@ inline int r3_ks_template(int ks)
         if (ks <= v) return v;
     return 0;
 }
-// element tiles per ring stage: stages of 16-26 KiB (three of them beside 68 KiB of wave buffers and the bias sums)
-__host__ __device__ constexpr int r3_group(int KS) { return KS <= 3 ? 4 : KS <= 4 ? 2 : 1; }
+// element tiles per ring stage: stages of 16-32 KiB (three of them beside 36 KiB of wave buffers and the bias sums)
+__host__ __device__ constexpr int r3_group(int KS) { return KS <= 4 ? 4 : KS <= 8 ? 2 : 1; }
 __host__ __device__ inline size_t r3_lds_bytes(int d, int KS) { return pad1k((size_t)d * 4) + 3 * (size_t)r3_group(KS) * KS * 2048 + (size_t)R3_NW * R3_WBUF; }
 
 // ------------------------------------------------------------------------------------------------ pack
@@ -75,16 +55,6 @@ __global__ void gram_pack_absmax_kernel(const float *w, size_t n, unsigned *out_
     }
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
 }
-
-// the exact power of two that brings `maxbits` (a float's bits) into [2^14, 2^15): its exponent T (a weight w goes in as w 2^T)
-__host__ __device__ inline int r3_shift_of(unsigned maxbits)
-{
-    const int e = (int)((maxbits >> 23) & 255u);      // max = 1.m x 2^(e - 127); zero / subnormal: no scaling worth doing
-    if (e == 0 || e == 255) return 0;
-    return 14 - (e - 127);
-}
-__device__ __forceinline__ float f32_bits(unsigned u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ float r3_pow2(int t) { return __builtin_bit_cast(float, (unsigned)((t + 127) << 23)); }     // -126 <= t <= 127
 
 // W_out image for v_mfma_f32_32x32x16_f16: fragment (mt, ks, piece) = 1 KiB = the A operand: lane l holds element 32 mt + (l & 31),
 // values k = 16 ks + 8 (l >> 5) + j, j = 0..7; value k = level k / c, component k % c (tight: no padding between levels), zero past
@@ -132,10 +102,10 @@ struct Rec3Params {
 // retire through one in-order counter); 0 = any plane width (p.cvs), values loaded at the tile's start.
 // The W_out stages form ONE stream over all tiles of the workgroup (the stage after a tile's last one is the next tile's first --
 // the same image), so nothing is drained or re-primed at a tile boundary.
-// Output: a PAIR of element tiles (32 tokens x 64 elements) at a time -- the two accumulators go through the wave's LDS buffer with
-// every lane writing (a ds_write_b128 occupies the LDS for its full 1-KiB slot however few lanes are active: the first form of this
-// kernel, with quarter-active writes of eight tiles at once, spent 0.33 of its 0.49 ms there), and leave as 4 token rows x 256
-// bytes per store instruction (5.80 TB/s on the full chip against 6.07 for 1-KiB rows, profiles/r02_store_patterns.txt).
+// Output: ONE element tile (32 tokens x 32 elements) at a time -- the accumulator goes through the wave's LDS buffer with every lane
+// writing (a ds_write_b128 occupies the LDS for its full 1-KiB slot however few lanes are active: the first form of this kernel,
+// with quarter-active writes of eight tiles at once, spent 0.33 of its 0.49 ms there), and leaves as 8 token rows x 128 bytes per
+// store instruction (5.82 TB/s on the full chip against 6.07 for 1-KiB rows, profiles/r02_store_patterns.txt).
 template <int KS, int CPF>
 __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
 {
@@ -143,13 +113,13 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
     constexpr int STAGE = G * KS * 2048;
     constexpr int NPC = G * KS * 2;                               // 1-KiB pieces per stage
     constexpr int NPB = NPC / R3_NW, NPX = NPC % R3_NW;           // per wave: NPB, one more on waves < NPX
-    constexpr int NSS = G == 4 ? 16 : 8;                          // store instructions per wave in a stage that completes pairs (G = 1: every second stage)
-    constexpr int NS2 = G == 4 ? 32 : G == 2 ? 16 : 8;            // ... in two consecutive stages
+    constexpr int NSS = 4 * G;                                    // store instructions per wave and stage (4 per element tile)
+    constexpr int NS2 = 2 * NSS;                                  // ... in two consecutive stages
     constexpr bool PREF = CPF != 0;
     constexpr int LM = PREF ? (16 * KS) / CPF : 1;                // levels a prefetching instantiation can hold (c == CPF)
     constexpr int NL = PREF ? (32 * CPF + 63) / 64 : 1;           // plane floats per lane and level (a wave's 32 tokens x CPF, lane-contiguous)
-    constexpr int TRS = 272;                                      // transposition rows: 64 elements x 4 bytes + 16
-    static_assert(32 * TRS <= R3_WBUF, "the pair's rows fit the wave's buffer");
+    constexpr int TRS = 144;                                      // transposition rows: 32 elements x 4 bytes + 16
+    static_assert(32 * TRS <= R3_WBUF, "the tile's rows fit the wave's buffer");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
@@ -324,75 +294,52 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * PFK, 0);
             }
         };
-        // a finished pair of element tiles (elements el0 .. el0 + 63 of the wave's 32 tokens): every lane writes its token's values,
-        // then 8 x (4 rows x 256 bytes) come back and leave with non-temporal stores
-        auto pair_out = [&](const f32x16 &a0, const f32x16 &a1, int el0) {
+        // a finished element tile (elements el0 .. el0 + 31 of the wave's 32 tokens): every lane writes its token's 16 values, then
+        // 4 x (8 rows x 128 bytes) come back and leave with non-temporal stores
+        auto tile_out = [&](const f32x16 &a0, int el0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
                 *reinterpret_cast<f32x4 *>(wbuf + r * TRS + (8 * i + 4 * h) * 4) = f32x4{a0[4 * i], a0[4 * i + 1], a0[4 * i + 2], a0[4 * i + 3]};
-                *reinterpret_cast<f32x4 *>(wbuf + r * TRS + (32 + 8 * i + 4 * h) * 4) = f32x4{a1[4 * i], a1[4 * i + 1], a1[4 * i + 2], a1[4 * i + 3]};
-            }
             wave_sync_lds();
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = 4 * i + (lane >> 4);
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(wbuf + row * TRS + (lane & 15) * 16);
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + (lane >> 3);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(wbuf + row * TRS + (lane & 7) * 16);
                 if ((R3_ABL & 2) ? p.n_tokens < 0 : (fullw || tw0 + row < tile_end))
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(orow + (size_t)row * p.d + el0 + (lane & 15) * 4));
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(orow + (size_t)row * p.d + el0 + (lane & 7) * 4));
             }
             wave_sync_lds();
         };
-        f32x16 acc_even;          // G == 1: the first tile of a pair waits here for the second (the next stage)
+        for (int s = 0; s < nstg; ++s) {
+            // This stage landed when only the pieces issued one stage ago are younger -- and the stores of the two stages between its
+            // issue and now (none before the kernel's first stage, one stage's worth before its second).  (The values prefetched for the
+            // next tile lie there too at a tile boundary; not counting them waits for a few operations more than needed, never fewer.)
+            if (!fullw) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ragged wave: its store count is not static
+            } else if (wave < NPX) {
+                if (sdone >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + NS2) : "memory");
+                else if (sdone == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + NSS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1) : "memory");
+            } else {
+                if (sdone >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NS2) : "memory");
+                else if (sdone == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NSS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();      // every wave's pieces of this stage landed; every wave has left the stage before
+            issue(s + 2, slot == 0 ? 2 : slot - 1);      // slot (s + 2) % 3 was read last in the stage before
+            const char *wb = smem + off_ring + slot * STAGE + lane * 16;
+            if (active) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc_even[i] = 0.0f;
-        for (int s0 = 0; s0 < nstg; s0 += (G == 1 ? 2 : 1)) {
-            static_for<0, (G == 1 ? 2 : 1)>([&](auto u_c) {
-                constexpr int U = decltype(u_c)::value;
-                const int s = s0 + U;
-                // This stage landed when only the pieces issued one stage ago are younger -- and the stores of the two stages between its
-                // issue and now (none before the kernel's first stage, one stage's worth before its second).  (The values prefetched
-                // for the next tile lie there too at a tile boundary; not counting them waits for a few operations more than needed,
-                // never fewer.)
-                constexpr int ST1 = G == 1 ? (U == 0 ? NSS : 0) : NSS;      // stores of the stage before this one
-                if (!fullw) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ragged wave: its store count is not static
-                } else if (wave < NPX) {
-                    if (sdone >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + NS2) : "memory");
-                    else if (sdone == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + ST1) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1) : "memory");
-                } else {
-                    if (sdone >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NS2) : "memory");
-                    else if (sdone == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + ST1) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB) : "memory");
+                for (int gi = 0; gi < G; ++gi) {
+                    const f32x16 a0 = tile_mm(wb, gi, s * G + gi);
+                    tile_order();
+                    // (the next tile's values before this tile's last stores: see CPF)
+                    if (PREF && gi == G - 1 && s == nstg - 1 && tile + gridDim.x < ntile) load_raw(tile + gridDim.x);
+                    tile_out(a0, (s * G + gi) * 32);
                 }
-                __builtin_amdgcn_s_barrier();      // every wave's pieces of this stage landed; every wave has left the stage before
-                issue(s + 2, slot == 0 ? 2 : slot - 1);      // slot (s + 2) % 3 was read last in the stage before
-                const char *wb = smem + off_ring + slot * STAGE + lane * 16;
-                if (active) {
-                    if constexpr (G == 1) {
-                        const f32x16 a = tile_mm(wb, 0, s);
-                        tile_order();
-                        if constexpr (U == 0) acc_even = a;
-                        else {
-                            // (the next tile's values before the tile's last stores: see CPF)
-                            if (PREF && s == nstg - 1 && tile + gridDim.x < ntile) load_raw(tile + gridDim.x);
-                            pair_out(acc_even, a, (s - 1) * 32);
-                        }
-                    } else {
-#pragma unroll
-                        for (int pr = 0; pr < G / 2; ++pr) {
-                            const f32x16 a0 = tile_mm(wb, 2 * pr, s * G + 2 * pr);
-                            tile_order();
-                            const f32x16 a1 = tile_mm(wb, 2 * pr + 1, s * G + 2 * pr + 1);
-                            tile_order();
-                            if (PREF && pr == G / 2 - 1 && s == nstg - 1 && tile + gridDim.x < ntile) load_raw(tile + gridDim.x);
-                            pair_out(a0, a1, (s * G + 2 * pr) * 32);
-                        }
-                    }
-                }
-                slot = slot == 2 ? 0 : slot + 1;
-                sdone = sdone < 2 ? sdone + 1 : 2;
-            });
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+            sdone = sdone < 2 ? sdone + 1 : 2;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stages issued past the last tile must have landed before the workgroup's LDS is handed on

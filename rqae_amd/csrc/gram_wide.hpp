@@ -80,8 +80,6 @@ template <> struct RowPtr<lds_cf32 *> {
 template <int CP, typename PT>
 __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, PT cbf)
 {
-    float xn[CP];
-    unit_dir<CP>(q, c, xn);
     const int nth = (n + 1) / 2 - 1;                    // thresholds: magnitudes above the lowest one
     const int base_pos = n / 2, base_neg = (n & 1) ? n / 2 : n / 2 - 1;
     // the row with every coordinate at its lowest magnitude, and what one step up in magnitude of coordinate j adds to the row index
@@ -100,6 +98,10 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
             }
         }
     }
+    // one magnitude (n = 2: C4): the row IS the sign pattern -- one candidate, nothing to score (a wave-uniform fact: n is a scalar)
+    if (nth == 0) return row0;
+    float xn[CP];
+    unit_dir<CP>(q, c, xn);
     // PW[t] = what raising the t coordinates of largest |q| by one magnitude adds: (|q_j|, step_j) sorted by descending |q_j| through a
     // compare-exchange network (5 exchanges at 4 coordinates, 9 at 5), then prefix sums.  Coordinates of exactly equal magnitude
     // may land either way round: the two rows then score the same in real arithmetic (a tie the reference decides by rounding)

@@ -33,6 +33,7 @@ int r3fail(const char *fmt, ...)
     } while (0)
 
 #include "gram_small.hpp"
+#include "gram_pieces.hpp"
 #include "gram_recon3.hpp"
 
 }  // namespace

@@ -196,8 +196,14 @@ def issued_mfma_flops_per_token(d, c, K, L, dtype, lattice):
     gl = 8 if cp <= 8 else 4
     gp = (gl * cp + 15) // 16 * 16
     nlg = (L + gl - 1) // gl
-    xp = {"bf16": 3, "f16": 6, "f32": 6}[dtype]           # piece products per weight fragment
-    proj = 2 * d * nlg * gp * xp
+    # projection: gram_proj3_kernel -- W_in as two fp16 pieces x (x as one fp16 piece: 2 products; fp32 x as two: 3), output tiles of 32
+    nog = nlg * gp // 16
+    ot = (nog + 1) // 2
+    if ot <= 8:
+        otk = 1 if ot <= 1 else 2 if ot <= 2 else 4 if ot <= 4 else 8
+        proj = 2 * d * otk * 32 * (3 if dtype == "f32" else 2)
+    else:
+        proj = 2 * d * nlg * gp * {"bf16": 3, "f16": 6, "f32": 6}[dtype]
     nkc = (6 * cp + 31) // 32
     scan = 0 if lattice else L * 2 * ((K + 15) // 16 * 16) * 32 * nkc
     # reconstruction: gram_recon3_kernel -- two fp16 pieces per value, three products, k-steps of 16 values (instantiated depths)

@@ -1369,7 +1369,7 @@ size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
     const long long tp = pad64(ch);
     // projections, TWO operand-row buffers (the pipelined schedule reconstructs pass i while pass i+1 fills the other one), dump
     // rows, timeline stamps (tools build)
-    return al256((size_t)g.NOG * tp * 16 * sizeof(float)) + 2 * al256(cv_row_bytes(g, levels) * tp) + 32768 + (2048 + 8 * 36 * 4) * 8 + LEV_STAMP_BYTES;
+    return al256((size_t)rqae_p3::padded_groups(g.NOG) * tp * 16 * sizeof(float)) + 2 * al256(cv_row_bytes(g, levels) * tp) + 32768 + (2048 + 8 * 36 * 4) * 8 + LEV_STAMP_BYTES;
 }
 
 bool levels_resident_ok(const Geom &g) { return g.shared_cb && (size_t)g.KTP * g.NKC * 1024 + ((size_t)g.K + 64) * g.c * 4 + 16 + B_NW * g.NKC * 4096 + (size_t)g.GL * g.GL * g.GB * 4 <= 158 * 1024; }
@@ -1569,7 +1569,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     const long long chunk = n_tokens < tuning().chunk ? n_tokens : tuning().chunk;
     const long long tp = pad64(chunk);
     float *P = static_cast<float *>(workspace);
-    unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)g.NOG * tp * 16 * sizeof(float)));
+    unsigned *cvimg = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + al256((size_t)rqae_p3::padded_groups(g.NOG) * tp * 16 * sizeof(float)));
     unsigned *cvimg2 = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(cvimg) + al256(cv_row_bytes(g, levels) * tp));
     float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(cvimg2) + al256(cv_row_bytes(g, levels) * tp));
 

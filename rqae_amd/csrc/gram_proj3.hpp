@@ -98,74 +98,93 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
     const int Tc = Tsh > 100 ? 100 : Tsh < -100 ? -100 : Tsh;
     const float isc = 1.0f / r3_pow2(Tc);
     const long long ntile = (p.n_tokens + P3_TILE - 1) / P3_TILE;
+    if ((long long)blockIdx.x >= ntile) return;
+    constexpr int NPS = 4 * OT + (NORM ? 1 : 0);     // P (and 1 / rms) stores per wave and tile (the workspace holds 2 OT groups: every store lands)
+    // x piece pc of a chunk = rows 8 pc .. 8 pc + 7 of the wave x 128 bytes; DMA lane i = (row i >> 3, slot i & 7) lands at piece +
+    // 16 i and fetches the row's 16-byte chunk (i & 7) ^ swz(row), swz(row) = (row >> 1) & 7: LDS slot j of a row holds source chunk
+    // j ^ swz, and the operand reads (lane (r, h): row r, chunk c) touch 16 distinct 16-byte slots of the 256-byte bank span per
+    // 16 lanes (rows of equal parity differ in swz)
+    auto offsets_of = [&](long long tile, unsigned (&vo)[XP]) {
+        const long long tile0 = tile * P3_TILE;
+        const long long tile_end = tile0 + P3_TILE < p.n_tokens ? tile0 + P3_TILE : p.n_tokens;
+#pragma unroll
+        for (int pc = 0; pc < XP; ++pc) {
+            const int row = 8 * pc + (lane >> 3);
+            long long rr = tile0 + (long long)wave * 32 + row;
+            rr = rr < tile_end ? rr : tile_end - 1;          // rows past the batch re-read its last row (never stored)
+            vo[pc] = (unsigned)((rr - tile0) * (long long)rowb) + (unsigned)((((lane & 7) ^ (row >> 1)) & 7) * 16);
+        }
+    };
+    // The x chunks and the W stages form ONE stream over all tiles of the workgroup: the chunk after a tile's last is the next tile's
+    // first, the W stage after the image's last is its first -- nothing is drained or re-primed at a tile boundary.
+    unsigned voff_i[XP];                             // offsets of the tile the x ISSUE stream is in
+    long long itile = blockIdx.x;                    // ... that tile
+    int ixc = 0;                                     // ... and its next chunk
+    offsets_of(itile, voff_i);
+    auto issue_x = [&](int slot) {
+        const void *xb = uniform_ptr(static_cast<const char *>(p.x) + (size_t)itile * P3_TILE * rowb + (size_t)ixc * 128);
+#pragma unroll
+        for (int pc = 0; pc < XP; ++pc) dma_piece_nt(xb, lds0 + off_xw + slot * 4096 + pc * 1024, voff_i[pc]);
+        if (++ixc == nxc) {                          // on to the next tile (past the last one: its last chunk again, static counts)
+            if (itile + gridDim.x < ntile) { itile += gridDim.x; ixc = 0; offsets_of(itile, voff_i); }
+            else ixc = nxc - 1;
+        }
+    };
+    auto issue_w = [&](int ws_in, int slot) {
+        const int ws = ws_in < nws ? ws_in : ws_in - nws;
+        for (int q = wave; q < NPC; q += P3_NW) {
+            const int k = q / (OT * 2), rem = q - k * (OT * 2);
+            int ot = rem >> 1;
+            ot = ot < p.OTT ? ot : p.OTT - 1;         // output tiles past the image (OT > OTT): any fragment, never used
+            dma_piece(uniform_ptr(p.wimg + (((size_t)(ws * KW + k) * p.OTT + ot) * 2 + (rem & 1)) * 512), lds0 + slot * STAGE + q * 1024, lane16);
+        }
+    };
+    // group s (a W stage) = { the x pieces of a chunk when s starts one, the W pieces of stage s + 2 }; the wave multiplies stage s when
+    // everything older than the newest group has landed
+    issue_x(0);
+    issue_w(0, 0);
+    if (WPX == 1) issue_x(1);
+    issue_w(1, 1);
+    int wslot = 0, xslot = 0;
+    unsigned xro[KX];        // operand read offsets inside an x slot: lane (r, h), k-step k -> chunk 2 k + h (2-byte x), 4 k + 2 h .. (fp32)
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const int cch = ESZ == 2 ? 2 * k + h : 4 * k + 2 * h;
+        xro[k] = (unsigned)(r * 128 + ((cch ^ (r >> 1)) & 7) * 16);
+    }
+    bool first_tile = true;
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const long long tile0 = tile * P3_TILE;
         const long long tile_end = tile0 + P3_TILE < p.n_tokens ? tile0 + P3_TILE : p.n_tokens;
         const long long tw0 = tile0 + (long long)wave * 32;
         const bool active = tw0 < tile_end;
+        const bool fullw = tw0 + 32 <= tile_end;
         f32x16 acc[OT];
 #pragma unroll
         for (int o = 0; o < OT; ++o)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[o][i] = 0.0f;
         float ssq = 0.0f;
-        // x piece pc of a chunk = rows 8 pc .. 8 pc + 7 of the wave x 128 bytes; DMA lane i = (row i >> 3, slot i & 7) lands at piece +
-        // 16 i and fetches the row's 16-byte chunk (i & 7) ^ swz(row), swz(row) = (row >> 1) & 7: LDS slot j of a row holds source chunk
-        // j ^ swz, and the operand reads (lane (r, h): row r, chunk c) touch 16 distinct 16-byte slots of the 256-byte bank span per
-        // 16 lanes (rows of equal parity differ in swz)
-        unsigned voff[XP];
-#pragma unroll
-        for (int pc = 0; pc < XP; ++pc) {
-            const int row = 8 * pc + (lane >> 3);
-            long long rr = tw0 + row;
-            rr = rr < tile_end ? rr : tile_end - 1;          // rows past the tile re-read its last row (never stored)
-            voff[pc] = (unsigned)((rr - tile0) * (long long)rowb) + (unsigned)((((lane & 7) ^ (row >> 1)) & 7) * 16);
-        }
-        const char *xtile = static_cast<const char *>(p.x) + (size_t)tile0 * rowb;
-        auto issue_x = [&](int xc_in, int slot) {
-            const int xc = xc_in < nxc ? xc_in : nxc - 1;
-            const void *xb = uniform_ptr(xtile + (size_t)xc * 128);
-#pragma unroll
-            for (int pc = 0; pc < XP; ++pc) dma_piece_nt(xb, lds0 + off_xw + slot * 4096 + pc * 1024, voff[pc]);
-        };
-        auto issue_w = [&](int ws_in, int slot) {
-            const int ws = ws_in < nws ? ws_in : nws - 1;
-            for (int q = wave; q < NPC; q += P3_NW) {
-                const int k = q / (OT * 2), rem = q - k * (OT * 2);
-                int ot = rem >> 1;
-                ot = ot < p.OTT ? ot : p.OTT - 1;         // output tiles past the image (OT > OTT): any fragment, never stored
-                dma_piece(uniform_ptr(p.wimg + (((size_t)(ws * KW + k) * p.OTT + ot) * 2 + (rem & 1)) * 512), lds0 + slot * STAGE + q * 1024, lane16);
-            }
-        };
-        // group s (a W stage) = { the x pieces of chunk (s + 2 WPX) / WPX when s starts a chunk, the W pieces of stage s + 2 }; the wave
-        // multiplies stage s when everything older than the newest group has landed
-        issue_x(0, 0);
-        issue_w(0, 0);
-        if (WPX == 1) issue_x(1, 1);
-        issue_w(1, 1);
-        int wslot = 0, xslot = 0;
-        unsigned xro[KX];        // operand read offsets inside an x slot: lane (r, h), k-step k -> chunk 2 k + h (2-byte x), 4 k + 2 h .. (fp32)
-#pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            const int cch = ESZ == 2 ? 2 * k + h : 4 * k + 2 * h;
-            xro[k] = (unsigned)(r * 128 + ((cch ^ (r >> 1)) & 7) * 16);
-        }
         for (int xc = 0; xc < nxc; ++xc) {
             static_for<0, WPX>([&](auto w_c) {
                 constexpr int WS = decltype(w_c)::value;
                 const int s = xc * WPX + WS;
-                // younger than what stage s needs: the group issued one stage ago -- its W pieces, and its x pieces where it carried some
+                // younger than what stage s needs: the group issued one stage ago -- its W pieces, and its x pieces where it carried
+                // some -- and the P stores of the tile before where they lie between (the tile's first two stages)
                 constexpr bool prev_had_x = WPX == 1 || WS == 1;       // the group before this one started an x chunk (WPX = 2: groups of even s do)
-                if (wave < NPX) {
-                    if (prev_had_x) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + XP) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1) : "memory");
+                const bool stores_between = !first_tile && s < 2;
+                if (!fullw) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ragged wave: its store count is not static
+                } else if (wave < NPX) {
+                    if (stores_between) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + (prev_had_x ? XP : 0) + NPS) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + (prev_had_x ? XP : 0)) : "memory");
                 } else {
-                    if (prev_had_x) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + XP) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB) : "memory");
+                    if (stores_between) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + (prev_had_x ? XP : 0) + NPS) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + (prev_had_x ? XP : 0)) : "memory");
                 }
                 __builtin_amdgcn_s_barrier();      // every wave's W pieces of stage s landed; every wave has left stage s - 1
                 // group s: x of the chunk two ahead (its slot was read last in the chunk before this one), W of stage s + 2
-                if (WS == 0) issue_x(xc + (WPX == 1 ? 2 : 1), WPX == 1 ? (xslot == 0 ? 2 : xslot - 1) : (xslot ^ 1));
+                if (WS == 0) issue_x(WPX == 1 ? (xslot == 0 ? 2 : xslot - 1) : (xslot ^ 1));
                 issue_w(s + 2, wslot == 0 ? 2 : wslot - 1);
                 if (active) {
                     const char *wb = smem + wslot * STAGE + lane * 16;
@@ -205,29 +224,27 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
                 if (WS == WPX - 1) xslot = NXS == 3 ? (xslot == 2 ? 0 : xslot + 1) : (xslot ^ 1);
             });
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated groups past the last chunk
-        // ---- projections out: lane (token r, half h) holds outputs 32 o + 8 i + 4 h + 0..3 -> P[group][tok][16]
+        // ---- projections out: lane (token r, half h) holds outputs 32 o + 8 i + 4 h + 0..3 -> P[group][tok][16]; NPS stores per wave
         float rs = 1.0f;
         if constexpr (NORM) {
             float v = ssq + __shfl_xor(ssq, 32);              // the two halves of a token's row
             rs = 1.0f / __builtin_sqrtf(v / (float)p.d + p.eps);
-            if (h == 0 && tw0 + r < tile_end) p.inv_rms[tw0 + r] = rs;
+            if (h == 0 && (fullw || tw0 + r < tile_end)) p.inv_rms[tw0 + r] = rs;
         }
         const float osc = isc * rs;
-        if (active && tw0 + r < tile_end) {
+        if (active && (fullw || tw0 + r < tile_end)) {
 #pragma unroll
             for (int o = 0; o < OT; ++o)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int u = 2 * o + (i >> 1);
-                    if (u < p.NOG)
-                        *reinterpret_cast<f32x4 *>(p.P + (((size_t)u * p.tok_pad + tw0 + r) * 16 + 8 * (i & 1) + 4 * h)) =
-                            f32x4{acc[o][4 * i] * osc, acc[o][4 * i + 1] * osc, acc[o][4 * i + 2] * osc, acc[o][4 * i + 3] * osc};
+                    const int u = 2 * o + (i >> 1);          // < 2 OT <= the workspace's groups (rounded up to whole tiles)
+                    *reinterpret_cast<f32x4 *>(p.P + (((size_t)u * p.tok_pad + tw0 + r) * 16 + 8 * (i & 1) + 4 * h)) =
+                        f32x4{acc[o][4 * i] * osc, acc[o][4 * i + 1] * osc, acc[o][4 * i + 2] * osc, acc[o][4 * i + 3] * osc};
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();     // the rings are free for the next tile
+        first_tile = false;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the groups issued past the last tile must have landed before the workgroup's LDS is handed on
 }
 
 // ------------------------------------------------------------------------------------------------ pack

@@ -10,6 +10,10 @@ namespace rqae_p3 {
 
 // output tiles of 32 for nog groups of 16 outputs
 inline int out_tiles(int nog) { return (nog + 1) / 2; }
+// output tiles the kernel instantiation for nog groups computes (1, 2, 4 or 8), and the groups of 16 outputs the projection buffer
+// must hold so that every one of its stores lands ([groups][tok_pad][16] floats)
+inline int kernel_tiles(int nog) { const int t = out_tiles(nog); return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : 8; }
+inline int padded_groups(int nog) { return out_tiles(nog) <= 8 ? 2 * kernel_tiles(nog) : nog; }
 // bytes of the W_in image: [d / 16][out_tiles][2 pieces][1 KiB]
 __attribute__((visibility("hidden"))) size_t image_bytes(int d, int nog);
 // max |W_in (x in_scale)| into *maxbits_dev (a zeroed device word), then the image; CP / GL / GP: the arm's output geometry

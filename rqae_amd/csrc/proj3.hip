@@ -68,7 +68,7 @@ int launch(const Args &a, int ncu, hipStream_t s)
     long long nb = (a.n_tokens + P3_TILE - 1) / P3_TILE;
     if (nb > ncu) nb = ncu;
     const int ott = pp.OTT;
-    const int otk = ott <= 1 ? 1 : ott <= 2 ? 2 : ott <= 4 ? 4 : 8;      // instantiated tile counts
+    const int otk = kernel_tiles(a.nog);      // instantiated tile counts
     const size_t lds = p3_lds_bytes(a.x_dtype, otk);
     auto go = [&](auto kern) -> int {
         P3_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

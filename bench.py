@@ -64,7 +64,7 @@ GRAM_MFMA_FLOPS_PER_TOKEN = 2 * D * 48 * 3 + L * 2 * K * 32 + 2 * D * 256
 
 PROFILE_ROUND = "r03"     # profiles/<round>_traffic.json, <round>_pmc_summary.json: the committed counter passes of this round
 
-KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "gram_wide.hpp", "gram_recon3.hpp", "gram_small.hpp", "gram_pieces.hpp", "recon3.hip", "gram_proj3.hpp", "proj3.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
+KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "gram_wide.hpp", "gram_recon3.hpp", "gram_small.hpp", "gram_pieces.hpp", "recon3.hip", "gram_proj3.hpp", "proj3.hip", "gram_deep3.hpp", "deep3.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
 
 
 def sources_hash():
@@ -219,13 +219,15 @@ def issued_mfma_flops_per_token(d, c, K, L, dtype, lattice):
 
 
 def config_leg(np, torch, device, name, cfg_name, tokens, dtype, what, steps=10, warmup=3, n_check=4096, options=None,
-               free_codebooks=False, arm="gram"):
+               free_codebooks=False, arm="gram", levels=None):
     """One BASELINE config through the product path: `steps` timed forwards (HIP events on the launch stream, synchronised both
     sides), the per-kernel split, both roofline fractions and a parity count against the oracle on the first `n_check` tokens."""
     import oracle
     from rqae_amd import RQAE, _native, synth
 
     cfg = dict(synth.CONFIGS[cfg_name])
+    if levels:
+        cfg["num_quantizers"] = levels
     if free_codebooks:
         rows = cfg["codebook_size"] ** cfg["codebook_dim"]
         w = synth.weights(1234, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], free_codebook_rows=rows)
@@ -265,7 +267,21 @@ def config_leg(np, torch, device, name, cfg_name, tokens, dtype, what, steps=10,
     roof = {"hbm_frac": hbm_frac, "hbm_GBs": tps * bytes_tok / 1e9,
             "algorithmic_flops_frac_of_bf16_peak": tps * flops_tok / 1e12 / PEAK_BF16_TFLOPS}
     shared = not free_codebooks
-    if arm != "exact" and shared:
+    if arm != "exact" and shared and L_ > 64:
+        # the blocked path of the deep shapes (gram_deep3.hpp): projection 2 pieces x d x L c, cross-block corrections L^2 c^2 / 2 x 3
+        # products (whole blocks of 32 levels), reconstruction L c x d x 3 products
+        try:
+            with torch.inference_mode():
+                ph = [_native.encode_gram_phases(model.gram_packed_weights(), model._dims(), x.view(tokens, -1)[:131072], L_, options=options)
+                      for _ in range(2)]
+            out["kernel_ms_per_131072_tokens"] = dict(zip(["project", "level chain + corrections", "reconstruct"], [float(np.median(v)) for v in zip(*ph)]))
+        except Exception as e:
+            out["kernel_ms_per_131072_tokens"] = f"unavailable: {e}"
+        nb = L_ // 32
+        issued = 2 * d * L_ * c * 2 + 2 * 128 * 128 * (nb * (nb - 1) // 2) * 3 + 2 * d * L_ * c * 3
+        roof["mfma_issued_flops_per_token"] = issued
+        roof["mfma_frac"] = tps * issued / 1e12 / PEAK_BF16_TFLOPS
+    elif arm != "exact" and shared:
         try:
             with torch.inference_mode():
                 ph = [_native.encode_gram_phases(model.gram_packed_weights(), model._dims(), x.view(tokens, -1), L_, options=options)
@@ -566,6 +582,17 @@ def main():
                     cfgs[name] = config_leg(np, torch, device, name, cname, ntok, dt, what)
                 except Exception as e:      # a leg that fails is reported, never hidden
                     cfgs[name] = {"what": what, "error": f"{type(e).__name__}: {e}"}
+            try:
+                cfgs["P1024/bf16"] = config_leg(np, torch, device, "P1024/bf16", "P", 262144, "bf16",
+                                                "the released model's shape at its full depth (rqae/model.py:18-24: d=2304, c=4, n=5, 1024 levels), 262144 "
+                                                "tokens, bf16 in: the matrix-core arm's blocked path (32-level blocks, corrections across blocks and the "
+                                                "reconstruction as K-streamed matrix products)", steps=3, warmup=1, n_check=512, levels=1024)
+                ex = config_leg(np, torch, device, "P1024/bf16 exact arm", "P", 32768, "bf16", "the same shape on the exact arm (canonical fp32 order)",
+                                steps=2, warmup=1, n_check=256, levels=1024, arm="exact")
+                cfgs["P1024/bf16"]["exact_arm"] = {k: ex[k] for k in ("tokens", "ms", "value", "parity")}
+                cfgs["P1024/bf16"]["speedup_vs_exact_arm"] = cfgs["P1024/bf16"]["value"] / ex["value"]
+            except Exception as e:
+                cfgs["P1024/bf16"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 cfgs["C2/scan"] = config_leg(np, torch, device, "C2/scan", "C2", 262144, "bf16",
                                              "configs[1]'s shape with the codebook SCANNED on the matrix cores (lean_levels=2: the path for any "

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQAE_HIP_ABI_VERSION 3
+#define RQAE_HIP_ABI_VERSION 4
 
 /* element type of the activation matrix x */
 enum { RQAE_X_F32 = 0, RQAE_X_BF16 = 1, RQAE_X_F16 = 2 };
@@ -258,6 +258,10 @@ int rqae_hip_encode_gram_gemma(const void *packed, int d, int c, int K, int L, i
  * written: 2 d + 2 d bytes per token move instead of 2 d + 4 d + (4 d + 2 d + 2 d).  inv_1pw [d] fp32 = 1 / (1 + norm.weight),
  * allocated in whole KiB; inv_rms [n_tokens] fp32 is scratch (it holds rs afterwards); levels <= 8.  Tier-2 parity for the codes;
  * the patched values within one rounding step of hs' dtype of the unfused path's. */
+/* 1 when rqae_hip_encode_gram_gemma_patch serves the call: levels <= 8 (one level group), 2-byte hs, and the level chain's tables fit
+ * LDS -- or, for a codebook rqae_hip_gram_lattice named an FSQ lattice and a call that passes lean_levels = 5 (lattice_vouched != 0),
+ * just its fp32 rows do (K = 4096 at c = 4).  0: take rqae_hip_encode_gram_gemma + rqae_hip_gemma_denorm_patch. */
+int rqae_hip_encode_gram_gemma_patch_supported(int d, int c, int K, int L, int codebook_shared, int levels, int hs_dtype, int lattice_vouched);
 int rqae_hip_encode_gram_gemma_patch(const void *packed, int d, int c, int K, int L, int codebook_shared, void *hs_inout, int hs_dtype,
                                      float eps, const float *inv_1pw, int S, int skip_bos, int64_t n_tokens, int levels,
                                      int64_t *indices, float *inv_rms, void *workspace, const rqae_hip_gram_options *options,

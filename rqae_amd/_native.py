@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RQAE_HIP_LIBRARY: another build of the same library (tools/: timeline and ablation builds); the product loads its own
 SO_PATH = os.environ.get("RQAE_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "librqae_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 IDX_I64, IDX_I32, IDX_U16 = 0, 1, 2
 
@@ -49,6 +49,7 @@ SYMBOLS = (
     "rqae_hip_encode_gram",
     "rqae_hip_encode_gram_gemma_supported",
     "rqae_hip_encode_gram_gemma",
+    "rqae_hip_encode_gram_gemma_patch_supported",
     "rqae_hip_encode_gram_gemma_patch",
     "rqae_hip_encode_gram_phases",
     "rqae_hip_decode_gram_supported",
@@ -145,6 +146,8 @@ def lib():
     L.rqae_hip_encode_gram_gemma_supported.restype = i
     L.rqae_hip_encode_gram_gemma.argtypes = [vp, i, i, i, i, i, vp, i, ctypes.c_float, i64, i, vp, vp, vp, vp, ctypes.POINTER(GramOptions), vp]
     L.rqae_hip_encode_gram_gemma.restype = i
+    L.rqae_hip_encode_gram_gemma_patch_supported.argtypes = [i, i, i, i, i, i, i, i]
+    L.rqae_hip_encode_gram_gemma_patch_supported.restype = i
     L.rqae_hip_encode_gram_gemma_patch.argtypes = [vp, i, i, i, i, i, vp, i, ctypes.c_float, vp, i, i, i64, i, vp, vp, vp,
                                                    ctypes.POINTER(GramOptions), vp]
     L.rqae_hip_encode_gram_gemma_patch.restype = i
@@ -358,6 +361,14 @@ def encode_gram_gemma(gpacked_scaled, dims, hs: torch.Tensor, eps: float, levels
                                                   _stream(hs.device))
         _check(rc, "rqae_hip_encode_gram_gemma")
     return q, idx, rs
+
+
+def encode_gram_gemma_patch_supported(dims, hs_dtype, levels: int, lattice_vouched: bool) -> bool:
+    """include/rqae_hip.h: rqae_hip_encode_gram_gemma_patch_supported (the in-place hook is gated on the conditions the
+    C side checks, not on the depth alone)."""
+    d, c, K, L_ = dims
+    return hs_dtype in _X_DTYPES and bool(lib().rqae_hip_encode_gram_gemma_patch_supported(d, c, K, L_, 1, int(levels), _X_DTYPES[hs_dtype],
+                                                                                          int(bool(lattice_vouched))))
 
 
 def encode_gram_gemma_patch(gpacked_scaled, dims, hs: torch.Tensor, inv_1pw: torch.Tensor, eps: float, levels: int, skip_bos: bool,

@@ -34,6 +34,7 @@
 #include "../../include/rqae_hip.h"
 #include "recon3.h"
 #include "proj3.h"
+#include "deep3.h"
 
 extern __attribute__((visibility("hidden"))) __thread char rqae_g_err[512];   // __thread, not thread_local: no TLS init wrapper (a hidden weak _ZTH call crashes)
 
@@ -57,7 +58,8 @@ int gfail(const char *fmt, ...)
 #include "gram_small.hpp"
 
 constexpr int GRAM_MAGIC = 0x4752414d;  // "GRAM"
-constexpr int GRAM_MAX_L = 64;
+constexpr int GRAM_MAX_L = 1024;       // calls of more than GRAM_DEEP_L levels take the blocked path of gram_deep3.hpp (c = 4, FSQ lattice)
+constexpr int GRAM_DEEP_L = 64;
 constexpr int GRAM_MAX_C = 13;          // instantiated: CP = 4, 5 (resident / streamed codebook), 13 (gram_wide.hpp: 6 <= c <= 13)
 
 // ------------------------------------------------------------------------------------------------ geometry
@@ -108,8 +110,12 @@ __host__ __device__ inline int nks_recon(const Geom &g, int levels)
     return full * (g.GS / 32) + (6 * g.CP * rem + 31) / 32;
 }
 
+// a block that can run more than GRAM_DEEP_L levels (gram_deep3.hpp): c = 4, whole blocks of 32 levels and whole column blocks of the
+// projection (L % 64 == 0), one shared codebook whose fp32 rows fit the lattice form's LDS
+inline bool deep_block_ok(const Geom &g) { return g.L > GRAM_DEEP_L && g.c == 4 && g.L % 64 == 0 && g.shared_cb && (size_t)g.K * g.c * 4 <= 150 * 1024 && g.d % 128 == 0; }
+
 struct GLayout {
-    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, wout3_img, win3_img, total;
+    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, wout3_img, win3_img, g3_img, total;
 };
 
 GLayout make_glayout(const Geom &g)
@@ -126,6 +132,7 @@ GLayout make_glayout(const Geom &g)
     lo.bias_prefix = off; off += al256(sizeof(float) * (size_t)g.L * g.d + 1024);                        // + 1 KiB: the fused kernel stages a row in whole 1-KiB pieces
     lo.wout3_img = off;   off += al256(rqae_r3::image_bytes(g.d, g.c, g.L));                              // fp16 two-piece W_out image (gram_recon3.hpp)
     lo.win3_img = off;    off += al256(rqae_p3::image_bytes(g.d, g.NOG));                                   // fp16 two-piece W_in image (gram_proj3.hpp)
+    lo.g3_img = off;      off += deep_block_ok(g) ? al256(rqae_d3::g3_bytes(g.L)) : 0;                              // fp16 two-piece image of -(W_in W_out) (gram_deep3.hpp)
     lo.total = off;
     return lo;
 }
@@ -136,7 +143,8 @@ struct GHeader {
     int lattice_miss[2];      // scratch of that check: rows that are not the unit-length lattice row / not the plain lattice row
     unsigned wout_maxbits;    // bits of max |W_out| (gram_pack_absmax_kernel): fixes the power-of-two scale of the fp16 image
     unsigned win_maxbits;     // the same for W_in (x in_scale)
-    int pad[53];
+    unsigned g3_maxbits;      // the same for the Gram blocks (gram_deep3.hpp)
+    int pad[52];
 };
 static_assert(sizeof(GHeader) == 256, "header");
 
@@ -739,9 +747,10 @@ struct LevParams {
     const uint16_t *cb_img;   // [lcb][KTP][NKC][512]
     const float *cb_f32;      // [lcb][K][c]
     unsigned *cvimg;          // [nks][tok_pad][16 dwords]: B operand rows of the reconstruction
-    long long *idx;           // [n_tokens][levels]
+    long long *idx;           // [n_tokens][idx_stride]
     long long n_tokens, tok_pad, ntiles;
     int levels, L, K, KTP, c, shared_cb;
+    int idx_stride;           // row length of idx (= levels, but for a block of a deeper call: gram_deep3.hpp)
     const int *lat_flag;      // the block's lattice word (GHeader::lattice_n: n >= 2 when the codebook is an FSQ lattice), or NULL
 };
 
@@ -1322,9 +1331,9 @@ int device_cus()
 
 struct GView {
     Geom g;
-    const uint16_t *win_img, *cb_img, *wout_img, *wout3_img, *win3_img;
+    const uint16_t *win_img, *cb_img, *wout_img, *wout3_img, *win3_img, *g3_img;
     const float *kconst, *gneg, *cb_f32, *bias_prefix;
-    const unsigned *wout_maxbits, *win_maxbits;
+    const unsigned *wout_maxbits, *win_maxbits, *g3_maxbits;
 };
 
 // the header lives on the device; the caller passes (d, c, K, L) again and the geometry is recomputed
@@ -1345,6 +1354,8 @@ GView gview(const void *packed, int d, int c, int K, int L, int shared_cb)
     v.wout_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, wout_maxbits));
     v.win3_img = reinterpret_cast<const uint16_t *>(b + lo.win3_img);
     v.win_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, win_maxbits));
+    v.g3_img = reinterpret_cast<const uint16_t *>(b + lo.g3_img);
+    v.g3_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, g3_maxbits));
     return v;
 }
 
@@ -1363,8 +1374,23 @@ size_t cv_row_bytes(const Geom &g, int levels)
     return a > planes ? a : planes;
 }
 
+constexpr long long GRAM_CHUNK_DEEP = 131072;  // tokens per pass of a deep call (32.5 KB of workspace per token at L = 1024: 4.3 GB a set)
+inline size_t deep_set_bytes(const Geom &g, long long tp)
+{
+    return al256((size_t)rqae_p3::padded_groups(g.NOG) * tp * 16 * sizeof(float)) + al256((size_t)rqae_d3::BLOCK_LEVELS * tp * 4 * sizeof(float)) +
+           al256(rqae_d3::pieces_bytes(tp, g.L));
+}
+
 size_t ws_bytes(const Geom &g, long long n_tokens, int levels)
 {
+    if (levels > GRAM_DEEP_L) {
+        // deep calls (gram_deep3.hpp): the projections of every level, fp32 planes of one block of levels, the operand fragments of
+        // every straight-through value, dump rows
+        const long long ch = n_tokens < GRAM_CHUNK_DEEP ? n_tokens : GRAM_CHUNK_DEEP;
+        const long long tp = pad64(ch);
+        // (two sets when the call runs in several passes: consecutive passes go down two streams, one's level chain beside the other's products)
+        return (n_tokens > GRAM_CHUNK_DEEP ? 2 : 1) * deep_set_bytes(g, tp) + 32768;
+    }
     const long long ch = n_tokens < GRAM_CHUNK ? n_tokens : GRAM_CHUNK;
     const long long tp = pad64(ch);
     // projections, TWO operand-row buffers (the pipelined schedule reconstructs pass i while pass i+1 fills the other one), dump
@@ -1446,8 +1472,11 @@ int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared)
 int rqae_hip_encode_gram_supported(int d, int c, int K, int L, int codebook_shared, int levels, int want_recon)
 {
     if (!rqae_hip_gram_supported(d, c, K, L, codebook_shared) || levels < 1 || levels > L) return 0;
-    if (!want_recon) return 1;
     const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
+    // more than 64 levels: the blocked path of gram_deep3.hpp (whole blocks of 32 levels of an FSQ lattice codebook, c = 4; the call
+    // must vouch for the lattice: lean_levels = 5)
+    if (levels > GRAM_DEEP_L) return deep_block_ok(g) && levels % rqae_d3::BLOCK_LEVELS == 0 && rqae_p3::supported(d, g.NOG, RQAE_X_BF16, false) ? 1 : 0;
+    if (!want_recon) return 1;
     if (rqae_r3::supported(d, c, levels) && (g.CP == 13 || levels <= 8)) return 1;      // gram_recon3_kernel behind the planes of the wide / lean level chains
     if (g.CP == 13) return levels <= 16 ? 1 : 0;
     return recon_nks_template(nks_recon(g, levels)) != 0 ? 1 : 0;
@@ -1507,6 +1536,9 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
     G_TRY(hipGetLastError());
     // the fp16 two-piece image of W_out (gram_recon3.hpp): its power-of-two scale follows from max |W_out|, found on the device
     if (int rc = rqae_r3::pack(b + lo.wout3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, wout_maxbits)), d, c, L, w_out, s)) return rc;
+    // ... of the Gram blocks for the cross-block corrections of deep calls (gram_deep3.hpp)
+    if (deep_block_ok(g))
+        if (int rc = rqae_d3::pack_g3(b + lo.g3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, g3_maxbits)), reinterpret_cast<const float *>(b + lo.gneg), L, g.GB, s)) return rc;
     // ... and of W_in (gram_proj3.hpp), in_scale folded in like the bf16 image's
     if (int rc = rqae_p3::pack(b + lo.win3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, win_maxbits)), d, c, L, g.CP, g.GL, g.GP, g.NOG, w_in, in_scale, s)) return rc;
     return 0;
@@ -1576,6 +1608,85 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     const bool p3_go = tuning().proj == 4 && rqae_p3::supported(d, g.NOG, x_dtype, inv_rms != nullptr);
     if (inv_rms && !p3_go && !(tuning().proj >= 3 && g.CP <= 5 && x_dtype != RQAE_X_F32 && d % 64 == 0))
         return gfail("encode_gram_gemma: the folded norm is served for bf16 / fp16 hidden states with d %% 64 == 0 (d=%d, x_dtype=%d)", d, x_dtype);
+    if (levels > GRAM_DEEP_L) {
+        // ---- deep calls (gram_deep3.hpp): blocks of 32 levels; across blocks the corrections are matrix products, as is the reconstruction
+        constexpr int BL = rqae_d3::BLOCK_LEVELS;
+        if (!deep_block_ok(g) || levels % BL) return gfail("encode_gram: %d levels need c = 4, L %% 64 == 0 and whole blocks of %d levels (L=%d c=%d)", levels, BL, L, c);
+        if (inv1pw) return gfail("encode_gram_gemma_patch: one level group only (levels <= 8)");
+        if (tuning().lattice != 2) return gfail("encode_gram: calls of more than %d levels run the lattice form alone: pass lean_levels = 5 for a block rqae_hip_gram_lattice named a lattice", GRAM_DEEP_L);
+        if (!p3_go) return gfail("encode_gram: the deep path needs the fp16 projection (proj = 4) for d=%d x_dtype=%d", d, x_dtype);
+        const int *latw = reinterpret_cast<const int *>(static_cast<const char *>(packed) + offsetof(GHeader, lattice_n));
+        const long long dchunk = n_tokens < GRAM_CHUNK_DEEP ? n_tokens : GRAM_CHUNK_DEEP;
+        const long long dtp = pad64(dchunk);
+        const int nblocks = levels / BL;
+        const int KSall = L * 4 / 16;
+        // Several passes: consecutive passes alternate between the caller's stream and a second one (two workspace sets).  A pass is a
+        // strict sequence of ~100 launches in which the level chain (one wave per SIMD at this pass size: latency-bound, 26 KB of LDS)
+        // alternates with matrix products (64-110 KB of LDS, two waves per SIMD): side by side, one pass's chain runs in the shadow
+        // of the other's products on the same CUs.
+        Side *sd = (!ev && n_tokens > dchunk) ? side_for_device() : nullptr;
+        std::unique_lock<std::mutex> side_lock;
+        if (sd) {
+            side_lock = std::unique_lock<std::mutex>(sd->mu);
+            G_TRY(hipEventRecord(sd->fork, s));
+            G_TRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
+        }
+        const hipStream_t s_main = s;
+        int pass_i = 0;
+        for (long long t0 = 0; t0 < n_tokens; t0 += dchunk, ++pass_i) {
+            const hipStream_t s = (sd && (pass_i & 1)) ? sd->st : s_main;       // (shadows the caller's stream inside the pass)
+            char *wset = static_cast<char *>(workspace) + ((sd && (pass_i & 1)) ? deep_set_bytes(g, dtp) : 0);
+            float *dP = reinterpret_cast<float *>(wset);
+            float *planes = reinterpret_cast<float *>(wset + al256((size_t)rqae_p3::padded_groups(g.NOG) * dtp * 16 * sizeof(float)));
+            char *pieces = reinterpret_cast<char *>(planes) + al256((size_t)BL * dtp * 4 * sizeof(float));
+            const long long nt = n_tokens - t0 < dchunk ? n_tokens - t0 : dchunk;
+            const bool mark = ev && t0 + dchunk >= n_tokens;
+            if (mark) G_TRY(hipEventRecord(ev[0], s));
+            rqae_p3::Args ap;
+            ap.img = v.win3_img; ap.maxbits = v.win_maxbits; ap.x = static_cast<const char *>(x) + (size_t)t0 * d * xs; ap.P = dP;
+            ap.inv_rms = inv_rms ? inv_rms + t0 : nullptr; ap.eps = eps; ap.n_tokens = nt; ap.tok_pad = dtp; ap.d = d; ap.nog = g.NOG; ap.x_dtype = x_dtype;
+            if (int rc = rqae_p3::launch(ap, ncu, s)) return rc;
+            if (mark) G_TRY(hipEventRecord(ev[1], s));
+            for (int b = 0; b < nblocks; ++b) {
+                if (b > 0) {
+                    // the block's 128 projection columns see every level before it: P[:, block] += CV[:, < 128 b] x G
+                    rqae_d3::Gemm gm;
+                    gm.apieces = pieces; gm.wimg = v.g3_img; gm.maxbits = v.g3_maxbits; gm.n_tokens = nt; gm.tok_pad = dtp; gm.KSA = KSall; gm.KSW = KSall;
+                    gm.nks = b * (BL * 4 / 16); gm.nt0 = b * (BL * 4 / 32); gm.ntiles = BL * 4 / 32; gm.P = dP; gm.bias = nullptr; gm.out = nullptr; gm.d = d;
+                    if (int rc = rqae_d3::corrections(gm, ncu, s)) return rc;
+                }
+                // the lattice form of the level chain on the block's 32 levels (four level groups: corrections between them through P)
+                LevParams pl;
+                pl.P = dP + (size_t)(b * (BL * 4 / 16)) * dtp * 16; pl.kconst = v.kconst + b * BL * 4;
+                pl.gneg = v.gneg + ((size_t)(b * BL) * L + b * BL) * g.GB; pl.cb_img = v.cb_img; pl.cb_f32 = v.cb_f32;
+                pl.cvimg = reinterpret_cast<unsigned *>(planes); pl.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels + b * BL;
+                pl.idx_stride = levels; pl.n_tokens = nt; pl.tok_pad = dtp; pl.ntiles = (nt + 63) / 64;
+                pl.levels = BL; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c; pl.shared_cb = 1; pl.lat_flag = latw;
+                long long nb = (pl.ntiles + 3) / 4;
+                if (nb > 8LL * ncu) nb = 8LL * ncu;
+                const size_t lds = (((size_t)K * c * 4 + 15) & ~(size_t)15) + (size_t)(BL / g.GL) * g.GL * g.GL * g.GB * 4;
+                if (lds > 64 * 1024) G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_levels_wide_kernel<4, 4, true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((gram_levels_wide_kernel<4, 4, true, false, true, true>), dim3((unsigned)nb), dim3(256), lds, s, pl);
+                G_TRY(hipGetLastError());
+                if (q_out || b + 1 < nblocks)
+                    if (int rc = rqae_d3::convert(planes, dtp, BL, b * BL, pieces, L, s)) return rc;
+            }
+            if (mark) G_TRY(hipEventRecord(ev[2], s));
+            if (q_out) {
+                rqae_d3::Gemm gm;
+                gm.apieces = pieces; gm.wimg = v.wout3_img; gm.maxbits = v.wout_maxbits; gm.n_tokens = nt; gm.tok_pad = dtp; gm.KSA = KSall; gm.KSW = g.KS3;
+                gm.nks = levels * 4 / 16; gm.nt0 = 0; gm.ntiles = d / 32; gm.P = nullptr; gm.bias = v.bias_prefix + (size_t)(levels - 1) * d;
+                gm.out = q_out + (size_t)t0 * d; gm.d = d;
+                if (int rc = rqae_d3::reconstruct(gm, ncu, s)) return rc;
+            }
+            if (mark) G_TRY(hipEventRecord(ev[3], s));
+        }
+        if (sd) {      // join: the caller's stream waits for the second one
+            G_TRY(hipEventRecord(sd->evC[0], sd->st));
+            G_TRY(hipStreamWaitEvent(s_main, sd->evC[0], 0));
+        }
+        return 0;
+    }
     if (!inv_rms && tuning().fused && x_dtype != RQAE_X_F32 && fused_shape_ok(g, levels)) {
         FusedParams pf;
         pf.x = x; pf.win_img = v.win_img; pf.kconst = v.kconst; pf.gneg = v.gneg; pf.cb_img = v.cb_img; pf.cb_f32 = v.cb_f32;
@@ -1621,11 +1732,14 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
     const bool patch = inv1pw != nullptr;
     // gram_recon3_kernel (fp16 two-piece operands): any shape whose values fit 16 k-steps, fed by fp32 planes
     const bool r3_want = q_out && !patch && tuning().recon == 3 && rqae_r3::supported(d, c, levels);
-    // one level group: the lean level chain hands fp32 straight-through values to the reconstruction (which splits them)
-    const bool lev2 = tuning().lev2 && g.CP <= 5 && levels <= 8 && g.shared_cb && g.NKC == 1 && lev2_lds_bytes(c, K) <= 160 * 1024 && (!q_out || recon2_ok || r3_want);
     // FSQ lattice codebooks: the lattice form first (it returns at once unless the block's header names a lattice), the scan kernel of
     // the shape behind it (it returns at once if the header does)
     const int *lat = tuning().lattice && g.shared_cb && (g.CP > 5 || (size_t)K * c * 4 <= 150 * 1024) ? reinterpret_cast<const int *>(static_cast<const char *>(packed) + offsetof(GHeader, lattice_n)) : nullptr;
+    // one level group: the lean level chain hands fp32 straight-through values to the reconstruction (which splits them).  The scan
+    // kernel behind the lattice form needs its tables in LDS (K <= ~1300); a caller who vouches for the lattice (lean_levels = 5) runs
+    // the lattice form alone, which needs only the fp32 rows there (K = 4096 at depth <= 8 used to fail the hook)
+    const bool lev2 = tuning().lev2 && g.CP <= 5 && levels <= 8 && g.shared_cb && g.NKC == 1 &&
+                      (lev2_lds_bytes(c, K) <= 160 * 1024 || (lat && tuning().lattice == 2)) && (!q_out || recon2_ok || r3_want);
     // narrow codebooks outside the lean path (several level groups, or a codebook too large for the scan's tables): the scan kernels
     // write bf16 operand rows, so fp32 planes for every level exist only when the caller vouches for a lattice (lean_levels = 5: the
     // lattice form runs alone)
@@ -1742,7 +1856,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pl.P = P; pl.kconst = v.kconst; pl.gneg = v.gneg; pl.cb_img = v.cb_img; pl.cb_f32 = v.cb_f32; pl.cvimg = cvimg;
             pl.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pl.n_tokens = nt; pl.tok_pad = tp; pl.ntiles = (nt + 63) / 64;
-            pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c; pl.shared_cb = 1; pl.lat_flag = lat;
+            pl.levels = levels; pl.L = L; pl.K = K; pl.KTP = g.KTP; pl.c = c; pl.shared_cb = 1; pl.lat_flag = lat; pl.idx_stride = levels;
             // narrow codebooks: 4 waves per workgroup, the fp32 rows and the Gram blocks inside each level group in LDS; wide ones: 8
             // waves, persistent, the whole upper triangle of Gram blocks in LDS (82 KB at depth 16: one workgroup per CU)
             const int nw = wide ? 8 : 4;
@@ -1774,7 +1888,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
             pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
-            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat;
+            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat; pb.idx_stride = levels;
             // 4 waves per workgroup (one per SIMD) until the batch fills the chip twice over: 8 then halve the image's L2 -> LDS traffic
 #ifdef W_FORCE_NW8   /* tools build: two waves per SIMD on half the CUs */
             const int nw = 8;
@@ -1799,7 +1913,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
             pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
             pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
-            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat;
+            pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat; pb.idx_stride = levels;
             const int nw = 8;
             const size_t lds = wide_levels_lds_bytes(g.NKC, nw);
             long long nb = (pb.ntiles + nw - 1) / nw;
@@ -1840,7 +1954,7 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
         pb.P = P; pb.kconst = v.kconst; pb.gneg = v.gneg; pb.cb_img = v.cb_img; pb.cb_f32 = v.cb_f32; pb.cvimg = cvimg;
         pb.idx = reinterpret_cast<long long *>(indices) + (size_t)t0 * levels;
         pb.n_tokens = nt; pb.tok_pad = tp; pb.ntiles = (nt + 63) / 64;
-        pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat;
+        pb.levels = levels; pb.L = L; pb.K = K; pb.KTP = g.KTP; pb.c = c; pb.shared_cb = g.shared_cb; pb.lat_flag = lat; pb.idx_stride = levels;
         if (g.CP <= 5 && g.NKC == 1 && (!g.shared_cb || (!levels_resident_ok(g) && g.CP == 4 && c == 4 && tuning().lev2 == 3))) {
             // per-level codebooks (levels_free_ok): every level streams its own image through the ring.  Also a
             // variant (lean_levels = 3) for a narrow codebook too large for LDS (C5: K 4096, depth 32): gram_wide.hpp's streamed form
@@ -2079,6 +2193,20 @@ int rqae_hip_encode_gram_gemma(const void *packed, int d, int c, int K, int L, i
 // norm folded into the projection, level chain, and the reconstruction kernel writes new = (q / (1 + w)) / rs over hs in its own
 // dtype, BOS rows (token % S == 0) kept when skip_bos.  `quantized` (fp32) is never written.  inv_1pw = 1 / (1 + norm.weight), [d]
 // padded to a whole KiB; inv_rms: [n_tokens] floats of scratch.
+// Can rqae_hip_encode_gram_gemma_patch serve this call?  One level group (levels <= 8), 2-byte hidden states, the token-stationary
+// reconstruction's LDS, and fp32 planes from the level chain: the scan kernel's tables must fit LDS (K <= ~1300) unless the caller
+// vouches for an FSQ lattice (lattice_vouched: rqae_hip_gram_lattice said so and the call passes lean_levels = 5), whose form needs
+// only the fp32 rows there.  0 -> run rqae_hip_encode_gram_gemma + rqae_hip_gemma_denorm_patch instead.
+int rqae_hip_encode_gram_gemma_patch_supported(int d, int c, int K, int L, int codebook_shared, int levels, int hs_dtype, int lattice_vouched)
+{
+    if (!rqae_hip_encode_gram_gemma_supported(d, c, K, L, codebook_shared, hs_dtype) || levels < 1 || levels > 8 || levels > L) return 0;
+    const Geom g = make_geom(d, c, K, L, codebook_shared ? 1 : 0);
+    if (g.CP > 5 || g.NKC != 1 || !g.shared_cb || d % 16) return 0;
+    if (2 * pad1k((size_t)d * 4) + 3 * (size_t)(g.CP == 4 ? FusedGeom<4>::STAGE_C : FusedGeom<5>::STAGE_C) + F_NW * F_TRW > 160 * 1024) return 0;
+    if (lev2_lds_bytes(c, K) <= 160 * 1024) return 1;
+    return lattice_vouched && (size_t)K * c * 4 <= 150 * 1024 ? 1 : 0;
+}
+
 int rqae_hip_encode_gram_gemma_patch(const void *packed, int d, int c, int K, int L, int codebook_shared, void *hs_inout, int hs_dtype,
                                      float eps, const float *inv_1pw, int S, int skip_bos, int64_t n_tokens, int levels,
                                      int64_t *indices, float *inv_rms, void *workspace, const rqae_hip_gram_options *options,

@@ -2,6 +2,8 @@
 // unit's anonymous namespace behind gram_small.hpp).  An fp32 value v, scaled by an exact power of two into fp16's range, is cut
 // into hi = rn16(v) and lo = rn16(v - hi): the remainder is below 2^-24 |v|, and hi*hi + hi*lo + lo*hi of two such values
 // reproduces their fp32 product to ~2^-23 -- three matrix products where three bf16 pieces per value needed six.
+constexpr int R3_CV_SHIFT = 10;          // straight-through values are scaled by 2^10 before they are cut into fp16 pieces (unit rows: |cv| <= 1 + one ulp of the projection)
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -34,4 +36,20 @@ __host__ __device__ inline int r3_shift_of(unsigned maxbits)
 }
 __device__ __forceinline__ float f32_bits(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ float r3_pow2(int t) { return __builtin_bit_cast(float, (unsigned)((t + 127) << 23)); }     // -126 <= t <= 127
+
+
+// largest |w| of an array as float bits (non-negative floats order like unsigned integers)
+__attribute__((unused)) __global__ void gram_pack_absmax_kernel(const float *w, size_t n, unsigned *out_bits)
+{
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = __builtin_fabsf(w[i]);
+        m = a > m ? a : m;        // NaN never wins: the image of a NaN weight is NaN whatever the scale
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
+}
 

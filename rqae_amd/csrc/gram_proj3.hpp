@@ -26,6 +26,7 @@ struct Proj3Params {
     float eps;
     long long n_tokens, tok_pad;
     int d, OTT, NOG;             // OTT: output tiles of 32 in the image (NOG 16-wide groups, rounded up to whole tiles)
+    int ny;                      // column blocks of OT output tiles (deep shapes: OTT > 8); the ny workgroups of a token tile share an XCD
 };
 
 constexpr int P3_NW = 8;
@@ -98,7 +99,18 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
     const int Tc = Tsh > 100 ? 100 : Tsh < -100 ? -100 : Tsh;
     const float isc = 1.0f / r3_pow2(Tc);
     const long long ntile = (p.n_tokens + P3_TILE - 1) / P3_TILE;
-    if ((long long)blockIdx.x >= ntile) return;
+    // XCD-aware mapping for several column blocks: consecutive workgroup ids go round the 8 XCDs, so ids that are equal mod 8 share an L2.
+    // The ny workgroups that take the same token tile through different output tiles get such ids and run at the same time: the
+    // tile's x comes from HBM once and from that XCD's L2 ny - 1 times (no non-temporal hint on it then).
+    long long tile_first = blockIdx.x, tile_step = gridDim.x;
+    int ot0 = 0;
+    if (p.ny > 1) {
+        const unsigned bid = blockIdx.x, xcd = bid & 7u, within = bid >> 3;
+        ot0 = (int)(within % (unsigned)p.ny) * OT;
+        tile_first = (long long)(within / (unsigned)p.ny) * 8 + xcd;
+        tile_step = gridDim.x / (unsigned)p.ny;
+    }
+    if (tile_first >= ntile) return;
     constexpr int NPS = 4 * OT + (NORM ? 1 : 0);     // P (and 1 / rms) stores per wave and tile (the workspace holds 2 OT groups: every store lands)
     // x piece pc of a chunk = rows 8 pc .. 8 pc + 7 of the wave x 128 bytes; DMA lane i = (row i >> 3, slot i & 7) lands at piece +
     // 16 i and fetches the row's 16-byte chunk (i & 7) ^ swz(row), swz(row) = (row >> 1) & 7: LDS slot j of a row holds source chunk
@@ -118,15 +130,20 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
     // The x chunks and the W stages form ONE stream over all tiles of the workgroup: the chunk after a tile's last is the next tile's
     // first, the W stage after the image's last is its first -- nothing is drained or re-primed at a tile boundary.
     unsigned voff_i[XP];                             // offsets of the tile the x ISSUE stream is in
-    long long itile = blockIdx.x;                    // ... that tile
+    long long itile = tile_first;                    // ... that tile
     int ixc = 0;                                     // ... and its next chunk
     offsets_of(itile, voff_i);
     auto issue_x = [&](int slot) {
         const void *xb = uniform_ptr(static_cast<const char *>(p.x) + (size_t)itile * P3_TILE * rowb + (size_t)ixc * 128);
+        if (p.ny > 1) {
 #pragma unroll
-        for (int pc = 0; pc < XP; ++pc) dma_piece_nt(xb, lds0 + off_xw + slot * 4096 + pc * 1024, voff_i[pc]);
+            for (int pc = 0; pc < XP; ++pc) dma_piece(xb, lds0 + off_xw + slot * 4096 + pc * 1024, voff_i[pc]);
+        } else {
+#pragma unroll
+            for (int pc = 0; pc < XP; ++pc) dma_piece_nt(xb, lds0 + off_xw + slot * 4096 + pc * 1024, voff_i[pc]);
+        }
         if (++ixc == nxc) {                          // on to the next tile (past the last one: its last chunk again, static counts)
-            if (itile + gridDim.x < ntile) { itile += gridDim.x; ixc = 0; offsets_of(itile, voff_i); }
+            if (itile + tile_step < ntile) { itile += tile_step; ixc = 0; offsets_of(itile, voff_i); }
             else ixc = nxc - 1;
         }
     };
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
         const int ws = ws_in < nws ? ws_in : ws_in - nws;
         for (int q = wave; q < NPC; q += P3_NW) {
             const int k = q / (OT * 2), rem = q - k * (OT * 2);
-            int ot = rem >> 1;
+            int ot = ot0 + (rem >> 1);
             ot = ot < p.OTT ? ot : p.OTT - 1;         // output tiles past the image (OT > OTT): any fragment, never used
             dma_piece(uniform_ptr(p.wimg + (((size_t)(ws * KW + k) * p.OTT + ot) * 2 + (rem & 1)) * 512), lds0 + slot * STAGE + q * 1024, lane16);
         }
@@ -153,7 +170,7 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
         xro[k] = (unsigned)(r * 128 + ((cch ^ (r >> 1)) & 7) * 16);
     }
     bool first_tile = true;
-    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    for (long long tile = tile_first; tile < ntile; tile += tile_step) {
         const long long tile0 = tile * P3_TILE;
         const long long tile_end = tile0 + P3_TILE < p.n_tokens ? tile0 + P3_TILE : p.n_tokens;
         const long long tw0 = tile0 + (long long)wave * 32;
@@ -229,7 +246,7 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
         if constexpr (NORM) {
             float v = ssq + __shfl_xor(ssq, 32);              // the two halves of a token's row
             rs = 1.0f / __builtin_sqrtf(v / (float)p.d + p.eps);
-            if (h == 0 && (fullw || tw0 + r < tile_end)) p.inv_rms[tw0 + r] = rs;
+            if (h == 0 && (fullw || tw0 + r < tile_end)) p.inv_rms[tw0 + r] = rs;      // (every column block writes the same value: one store either way, the waits count it)
         }
         const float osc = isc * rs;
         if (active && (fullw || tw0 + r < tile_end)) {
@@ -237,7 +254,7 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
             for (int o = 0; o < OT; ++o)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int u = 2 * o + (i >> 1);          // < 2 OT <= the workspace's groups (rounded up to whole tiles)
+                    const int u = 2 * (ot0 + o) + (i >> 1);  // < the workspace's groups (rounded up to whole tiles)
                     *reinterpret_cast<f32x4 *>(p.P + (((size_t)u * p.tok_pad + tw0 + r) * 16 + 8 * (i & 1) + 4 * h)) =
                         f32x4{acc[o][4 * i] * osc, acc[o][4 * i + 1] * osc, acc[o][4 * i + 2] * osc, acc[o][4 * i + 3] * osc};
                 }

@@ -24,7 +24,6 @@
 constexpr int R3_NW = 8;                 // waves per workgroup
 constexpr int R3_TILE = R3_NW * 32;      // tokens per tile
 constexpr int R3_WBUF = 4608;            // bytes of LDS per wave: piece build / transposition of one element tile (32 rows x 144)
-constexpr int R3_CV_SHIFT = 10;          // straight-through values are scaled by 2^10 before they are cut into fp16 pieces
 constexpr int R3_BK = 2;                 // k-steps per trip of the piece build through the wave's buffer
 
 // k-steps (of 16 values) the reconstruction of `levels` levels runs over, and the instantiated depths
@@ -41,21 +40,6 @@ __host__ __device__ constexpr int r3_group(int KS) { return KS <= 4 ? 4 : KS <= 
 __host__ __device__ inline size_t r3_lds_bytes(int d, int KS) { return pad1k((size_t)d * 4) + 3 * (size_t)r3_group(KS) * KS * 2048 + (size_t)R3_NW * R3_WBUF; }
 
 // ------------------------------------------------------------------------------------------------ pack
-// largest |W_out| as float bits (non-negative floats order like unsigned integers)
-__global__ void gram_pack_absmax_kernel(const float *w, size_t n, unsigned *out_bits)
-{
-    float m = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float a = __builtin_fabsf(w[i]);
-        m = a > m ? a : m;        // NaN never wins: the image of a NaN weight is NaN whatever the scale
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const float t = __shfl_xor(m, o);
-        m = t > m ? t : m;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
-}
-
 // W_out image for v_mfma_f32_32x32x16_f16: fragment (mt, ks, piece) = 1 KiB = the A operand: lane l holds element 32 mt + (l & 31),
 // values k = 16 ks + 8 (l >> 5) + j, j = 0..7; value k = level k / c, component k % c (tight: no padding between levels), zero past
 // L c; every weight scaled by 2^T (T from the header word gram_pack_absmax_kernel left).

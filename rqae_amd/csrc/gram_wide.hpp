@@ -772,7 +772,7 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
             if (live && t < p.n_tokens) {
 #pragma unroll
                 for (int li = 0; li < GL; ++li)
-                    if (lg * GL + li < p.levels) p.idx[t * p.levels + lg * GL + li] = (long long)codes[li];
+                    if (lg * GL + li < p.levels) p.idx[t * p.idx_stride + lg * GL + li] = (long long)codes[li];
             }
             // ---- projections of the later level groups see this group's levels
             W_T(t_m0);

@@ -19,7 +19,7 @@ __attribute__((visibility("hidden"))) size_t image_bytes(int d, int nog);
 // max |W_in (x in_scale)| into *maxbits_dev (a zeroed device word), then the image; CP / GL / GP: the arm's output geometry
 __attribute__((visibility("hidden"))) int pack(void *img, unsigned *maxbits_dev, int d, int c, int L, int CP, int GL, int GP, int nog,
                                                const float *w_in, const float *in_scale, hipStream_t stream);
-// one launch covers up to 8 output tiles (256 outputs)
+// one workgroup covers up to 8 output tiles (256 outputs); deeper shapes run whole column blocks of 8 tiles side by side
 __attribute__((visibility("hidden"))) bool supported(int d, int nog, int x_dtype, bool norm);
 
 struct Args {

@@ -54,7 +54,7 @@ int pack(void *img, unsigned *maxbits_dev, int d, int c, int L, int CP, int GL, 
 bool supported(int d, int nog, int x_dtype, bool norm)
 {
     const int ot = out_tiles(nog);
-    if (d % 128 != 0 || ot < 1 || ot > 8) return false;
+    if (d % 128 != 0 || ot < 1 || (ot > 8 && ot % 8 != 0)) return false;      // beyond 8 tiles: whole column blocks of 8
     if (norm && x_dtype == RQAE_X_F32) return false;
     return true;
 }
@@ -65,10 +65,22 @@ int launch(const Args &a, int ncu, hipStream_t s)
     Proj3Params pp;
     pp.x = a.x; pp.wimg = static_cast<const uint16_t *>(a.img); pp.maxbits = a.maxbits; pp.P = a.P; pp.inv_rms = a.inv_rms; pp.eps = a.eps;
     pp.n_tokens = a.n_tokens; pp.tok_pad = a.tok_pad; pp.d = a.d; pp.OTT = out_tiles(a.nog); pp.NOG = a.nog;
-    long long nb = (a.n_tokens + P3_TILE - 1) / P3_TILE;
-    if (nb > ncu) nb = ncu;
+    const long long ntl = (a.n_tokens + P3_TILE - 1) / P3_TILE;
     const int ott = pp.OTT;
-    const int otk = kernel_tiles(a.nog);      // instantiated tile counts
+    const int otk = ott > 8 ? 8 : kernel_tiles(a.nog);      // instantiated tile counts
+    long long nb;
+    pp.ny = 1;
+    if (ott > 8) {
+        // column blocks of 8 output tiles: the ny workgroups of a token tile get ids equal mod 8 (one XCD, one L2)
+        pp.ny = ott / 8;
+        long long gx = (ncu / pp.ny) & ~7LL;                 // token tiles in flight: a multiple of 8 (one id residue per XCD)
+        if (gx < 8) gx = 8;
+        const long long need = (ntl + 7) & ~7LL;
+        if (gx > need) gx = need;
+        nb = gx * pp.ny;
+    } else {
+        nb = ntl < ncu ? ntl : ncu;
+    }
     const size_t lds = p3_lds_bytes(a.x_dtype, otk);
     auto go = [&](auto kern) -> int {
         P3_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

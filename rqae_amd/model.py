@@ -52,6 +52,7 @@ class RQAE(nn.Module):
     """Residual-quantisation autoencoder; see module docstring for the mapping."""
 
     GRAM_MIN_TOKENS = 16384   # arm="auto": below this the exact arm's single launch wins
+    GRAM_MIN_TOKENS_DEEP = 32768   # ... for calls of more than 64 levels (the blocked path: ~100 launches per pass of 131072 tokens)
 
     PRETRAINED = {
         "google/gemma-2-2b": "harish-kamath/rqae/gemma-2-2b",
@@ -295,7 +296,7 @@ class RQAE(nn.Module):
                                    f"{' with reconstruction' if want_recon else ''} "
                                    "(include/rqae_hip.h: rqae_hip_encode_gram_supported); use arm='exact' or 'auto'")
             return True
-        return ok and n_tokens >= self.GRAM_MIN_TOKENS
+        return ok and n_tokens >= (self.GRAM_MIN_TOKENS_DEEP if levels > 64 else self.GRAM_MIN_TOKENS)
 
     def gram_packed_weights(self) -> torch.Tensor:
         """The matrix-core arm's own parameter block (include/rqae_hip.h: rqae_hip_gram_pack), cached like
@@ -657,7 +658,9 @@ class RQAE(nn.Module):
                 ws = self._gram_ws
                 if ws is None or ws.device != hs_llm.device or ws.numel() < need:
                     ws = self._gram_ws = torch.empty(need, dtype=torch.uint8, device=hs_llm.device)
-                if replace and self.num_quantizers <= 8:
+                gp = self.gram_packed_weights_scaled(final_norm.weight)
+                vouched = self.__dict__.get("gram_options") is None and getattr(gp, "lattice_n", 0) >= 2      # default options: lean_levels = 5
+                if replace and _native.encode_gram_gemma_patch_supported(self._dims(), hs_llm.dtype, self.num_quantizers, vouched):
                     # ... and the way back folded into the reconstruction's stores: hs is patched in place, `quantized` never exists
                     inv = self.__dict__.get("_gemma_inv")
                     if inv is None or inv[0] is not final_norm.weight or inv[1] != final_norm.weight._version:

@@ -39,7 +39,20 @@ def case_inputs(g):
     return cfg, w, x
 
 
-FORWARD_CASES = ["fwd_c1", "fwd_c2", "fwd_c2_bf16", "fwd_c2_max3", "fwd_c4", "fwd_c5", "fwd_p", "fwd_ragged"]
+def hook_4x128_inputs():
+    """The production-shaped hook capture (tests/golden/make_golden_r4.py: B=4, S=128, scripts/1_create_activations.py:152): the fp16
+    hidden states regenerate from their seed (sha256 guard); returns (fixture, hs [4,128,d] fp16)."""
+    from rqae_amd import synth
+
+    h = load_golden("hook_c2_4x128")
+    m = h["meta"]
+    cfg = synth.CONFIGS[m["cfgname"]]
+    hs = (synth.activations(m["seed_hs"], m["B"] * m["S"], cfg["dim"]) * m["hs_scale"]).astype(np.float16).reshape(m["B"], m["S"], cfg["dim"])
+    assert synth.sha256_of(hs) == str(h["hs_sha256"]), "synth.activations is not bit-stable on this host"
+    return h, hs
+
+
+FORWARD_CASES = ["fwd_c1", "fwd_c2", "fwd_c2_bf16", "fwd_c2_max3", "fwd_c4", "fwd_c5", "fwd_p", "fwd_ragged", "fwd_p128", "fwd_p1024"]
 
 
 def rel_err(a, b):

@@ -605,6 +605,50 @@ def test_weight_edits_are_seen_at_once_on_the_released_1024_level_module():
     assert np.array_equal(after, oracle.forward(x, w2, max_layers=24)[1])
 
 
+@pytest.mark.parametrize("name", ["fwd_p128", "fwd_p1024"])
+def test_gram_deep_levels_against_the_reference_captures(name):
+    """the released shape (d 2304, c 4, n 5: rqae/model.py:18-24) beyond 64 levels on the matrix cores
+    (gram_deep3.hpp: blocks of 32 levels, corrections across blocks and the reconstruction as K-streamed matrix products) against
+    the reference's own captures at depth 128 and at the full depth 1024 (tests/golden/make_golden_r4.py)."""
+    g = load_golden(name)
+    cfg, w, x = case_inputs(g)
+    m = make_model(cfg, w, "gram")
+    q, idx, xs = run(m, x, torch.float32)
+    listed = check_tier2(xs, w, q, idx)
+    bad = (idx != g["codes"].astype(np.int64)).any(axis=1)
+    assert bad.sum() == listed, f"{bad.sum()} tokens differ from the reference capture, {listed} listed"
+    ok = ~bad
+    rows = g["rows"][ok[g["rows"]]]
+    sel = np.isin(g["rows"], rows)
+    assert row_rel(q[rows], g["q_rows"][sel]) < RTOL
+
+
+def test_gram_released_shape_depth_1024():
+    """RQAE(2304, 4, 5, 1024) -- the default constructor, the only shape scripts/1_create_activations.py:144-186 and demo/server run --
+    on the matrix-core arm: 3 000 bf16 tokens against the oracle (Tier 2, every differing token adjudicated), a ragged batch, a
+    shallower call (max_layers = 96: three blocks) with the prefix property, codes only, and determinism."""
+    cfg = dict(dim=2304, codebook_dim=4, codebook_size=5, num_quantizers=1024)
+    w = synth.weights(77, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    x = synth.activations(4242, 3000, cfg["dim"])
+    q, idx, xs = run(m, x, torch.bfloat16)
+    listed = check_tier2(xs, w, q, idx)
+    # 3 M token-levels: a token-level in ~2e5 has two distinct rows within 1e-5 of each other (the reference itself flips one token in
+    # 3e4 at depth 8 under a change of summation order, SURVEY section 7), and a token that parts from the oracle there follows its own
+    # path through every deeper level -- each one adjudicated above as the float64 argmax path of its own codes
+    assert listed <= 40
+    q2, idx2, _ = run(m, x, torch.bfloat16)
+    assert np.array_equal(idx, idx2) and np.array_equal(q, q2)
+    q96, idx96, _ = run(m, x[:777], torch.bfloat16, max_layers=96)
+    assert np.array_equal(idx96, idx[:777, :96])
+    check_tier2(xs[:777], w, q96, idx96, levels=96)
+    with torch.inference_mode():
+        only = m.encode(torch.from_numpy(x[:300]).to(DEV).to(torch.bfloat16).view(1, 300, -1))
+    assert np.array_equal(only.cpu().numpy().reshape(300, -1), idx[:300])
+    qf, idxf, xf = run(m, x[:500], torch.float32)
+    check_tier2(xf, w, qf, idxf)
+
+
 def test_gram_captures_into_a_hip_graph():
     cfg = synth.CONFIGS["C2"]
     w = synth.weights(3, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
@@ -785,6 +829,38 @@ def test_gemma_hook_on_the_matrix_core_arm(dtype, B, S):
     # (normed there is rounded to the LLM dtype before the projection, here it never is: a token in a few hundred sits close enough
     #  to a tie for that to decide it)
     assert int((st_s["indices"] != idx_g).any(-1).sum()) <= max(1, n // 300)
+
+
+def test_gemma_hook_in_place_with_a_codebook_too_large_for_the_scan_tables():
+    """K = 4096 (c 4, n 8) at depth 8 -- the scan kernel's tables do not fit LDS, the lattice form's fp32 rows do.  The
+    in-place hook (rqae_hip_encode_gram_gemma_patch) is gated on rqae_hip_encode_gram_gemma_patch_supported, serves this shape when
+    the block is a lattice, and refuses cleanly (never raises inside the LLM's forward hook) otherwise."""
+    cfg = dict(dim=1024, codebook_dim=4, codebook_size=8, num_quantizers=8)
+    w = synth.weights(31, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    mg_, me_ = make_model(cfg, w, "gram"), make_model(cfg, w, "exact")
+    dims = mg_._dims()
+    assert _native.encode_gram_gemma_patch_supported(dims, torch.float16, 8, True)
+    assert not _native.encode_gram_gemma_patch_supported(dims, torch.float16, 8, False)
+    assert not _native.encode_gram_gemma_patch_supported(dims, torch.float32, 8, True)
+    d, B, S = cfg["dim"], 3, 700
+    rng = np.random.Generator(np.random.PCG64(9))
+    nw = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    llm = _FakeGemma2LLM(torch.from_numpy(nw).to(DEV))
+    hs0 = (torch.from_numpy(synth.activations(77, B * S, d)) * 3.0).to(torch.float16).view(B, S, d).to(DEV)
+    outs = {}
+    for name, m in (("gram", mg_), ("exact", me_)):
+        hs = hs0.clone()
+        st = {}
+        with torch.inference_mode():
+            m.hook(llm=llm, **(dict(store=lambda k, v: st.update({k: v})) if name == "exact" else {}))(None, None, (hs,))
+        torch.cuda.synchronize()
+        outs[name] = (hs, st)
+    assert "_gemma_inv" in mg_.__dict__                       # the in-place path ran
+    hs_g, hs_e = outs["gram"][0], outs["exact"][0]
+    assert torch.equal(hs_g[:, 0], hs0[:, 0])
+    rel = ((hs_g.float() - hs_e.float()).abs().amax(-1) / hs_e.float().abs().amax(-1).clamp_min(1e-30))
+    assert float((rel > 2.0 ** -10).float().mean()) < 0.01    # same tokens to fp16 rounding but for a rare low-margin one
+
 
 
 def test_operators_see_weights_restacked_after_an_update():

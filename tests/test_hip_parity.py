@@ -158,7 +158,7 @@ def test_quantize_known_answers_and_random():
         assert np.array_equal(idx.cpu().numpy(), idx_o) and np.array_equal(cv.cpu().numpy(), cv_o)
 
 
-@pytest.mark.parametrize("name", ["fwd_c1", "fwd_c2", "fwd_p", "fwd_c4"])
+@pytest.mark.parametrize("name", ["fwd_c1", "fwd_c2", "fwd_p", "fwd_c4", "fwd_p128"])
 def test_decode(name):
     g = load_golden(name)
     cfg, w, x = case_inputs(g)
@@ -240,6 +240,36 @@ def test_hook_call_sequence():
         m.hook(norm=llm.norm)
     with pytest.raises(AssertionError):
         m.hook(llm=object())
+
+
+def test_hook_at_the_production_call_shape():
+    """The reference's own hook capture at B=4, S=128 (scripts/1_create_activations.py:152; tests/golden/make_golden_r4.py): the generic
+    hook (store callback: the reference's code path with the HIP forward inside) reproduces every code of the 512 tokens and the
+    sampled rows of quantized / new / patched; the fused Gemma hook patches the layer output to within a rare last-bit flip of fp16."""
+    from conftest import hook_4x128_inputs
+
+    h, hs_np = hook_4x128_inputs()
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(h["meta"]["seed_w"], cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w)
+    B, S, d = hs_np.shape
+    rows = h["rows"]
+    llm = FakeGemma(torch.from_numpy(h["norm_weight"]).to(DEV))
+    store = {}
+    layer = FakeGemmaLayer()
+    handle = layer.register_forward_hook(m.hook(llm=llm, store=lambda k, v: store.update({k: v})))
+    with torch.inference_mode():
+        out = layer(torch.from_numpy(hs_np).to(DEV))
+    handle.remove()
+    torch.cuda.synchronize()
+    assert np.array_equal(store["indices"].cpu().numpy(), h["indices"].astype(np.int64))
+    flat = lambda t: t.reshape(B * S, d).cpu().numpy()[rows]      # noqa: E731
+    assert rel_err(flat(store["normed"]), h["normed_rows"]) < 1e-6
+    assert rel_err(flat(store["quantized"]), h["quantized_rows"]) < RTOL
+    assert rel_err(flat(store["new"]), h["new_rows"]) < 1e-5
+    assert (flat(out[0]) != h["patched_rows"]).mean() < 1e-3
+    bos = np.isin(rows, np.arange(0, B * S, S))
+    assert np.array_equal(flat(out[0])[bos], h["patched_rows"][bos])       # skip_bos: the layer's own rows
 
 
 def test_full_size_properties():

@@ -113,6 +113,29 @@ def test_hook_fixture_forward():
     assert np.array_equal(h["patched"], h["new"].astype(np.float16))  # output[0].data.copy_(q_out), fp16
 
 
+def test_hook_fixture_at_the_production_call_shape():
+    """the reference's own hook capture at B=4, S=128 (scripts/1_create_activations.py:152) -- every code of
+    the 512 tokens, and normed / quantized / new / patched on sampled rows (BOS rows included)."""
+    from conftest import hook_4x128_inputs
+
+    h, hs = hook_4x128_inputs()
+    cfg = synth.CONFIGS["C2"]
+    w = synth.weights(h["meta"]["seed_w"], cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    B, S, d = hs.shape
+    rows = h["rows"]
+    normed = oracle.gemma_norm(hs.astype(np.float32), h["norm_weight"]).reshape(B * S, d)
+    assert rel_err(normed[rows], h["normed_rows"]) < 1e-6
+    q, idx = oracle.forward(normed, w)
+    assert np.array_equal(idx.reshape(B, S, -1), h["indices"].astype(np.int64))
+    assert rel_err(q[rows], h["quantized_rows"]) < RTOL
+    new = oracle.gemma_denorm(q.reshape(B, S, d), hs.astype(np.float32), h["norm_weight"])
+    new[:, 0] = hs[:, 0].astype(np.float32)
+    new = new.reshape(B * S, d)
+    assert rel_err(new[rows], h["new_rows"]) < RTOL
+    assert np.array_equal(h["patched_rows"], h["new_rows"].astype(np.float16))
+    assert np.array_equal(h["patched_rows"][np.isin(rows, np.arange(0, B * S, S))], hs.reshape(B * S, d)[np.arange(0, B * S, S)])   # BOS rows kept
+
+
 def test_empty_and_single_token():
     cfg = synth.CONFIGS["C1"]
     w = synth.weights(1, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
@@ -178,7 +201,7 @@ def test_tables_against_reference_capture(tag):
     assert np.abs(oracle.layer_norms(w) / g[tag + "_layer_norms"] - 1).max() < 1e-6
 
 
-@pytest.mark.parametrize("name", ["fwd_c1", "fwd_c2", "fwd_c2_max3", "fwd_c5", "fwd_p", "fwd_ragged"])
+@pytest.mark.parametrize("name", ["fwd_c1", "fwd_c2", "fwd_c2_max3", "fwd_c5", "fwd_p", "fwd_ragged", "fwd_p128"])
 def test_torch_ops_restatement_matches_reference(name):
     """oracle/torch_ops.py (bench.py's cpu_baseline of kind "reference-ops": the reference's operator sequence) against
     the reference captures: the same ATen operators on the same values, so codes AND reconstruction rows are the capture's bits."""

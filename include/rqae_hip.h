@@ -211,6 +211,14 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
                        const float *codebook, const float *w_out, const float *b_out, int codebook_shared,
                        const float *in_scale /* [d] or NULL: a diagonal map in front of lin_in, folded into the W_in image */,
                        void *stream);
+/* RQAE.normalize_codebooks as a `levels`-level forward applies it (rqae/model.py:126-131, called once per level from quantize, :196;
+ * any quantization_method but the FSQ lattices): codebook [L][K][c] fp32 is renormalised `levels` times IN PLACE (every level's rows,
+ * as the reference does), and used_out [L][K][c] (or NULL) receives for each level l < levels its rows after l + 1 renormalisations
+ * -- what that level is quantised against.  One launch; torch-CPU's order of the row norm and IEEE divisions: the reference's bits.
+ * rqae_hip_gram_repack_codebooks rebuilds just the codebook part (images + fp32 rows) of a block packed with codebook_shared = 0 from
+ * such per-level rows; the linear maps' images and the Gram blocks stay. */
+int rqae_hip_normalize_codebooks(float *codebook, int L, int K, int c, int levels, float *used_out, void *stream);
+int rqae_hip_gram_repack_codebooks(void *packed, int d, int c, int K, int L, const float *codebook, void *stream);
 /* n >= 2 when rqae_hip_gram_pack found the block's (shared) codebook to be the FSQ lattice {linspace(-1, 1, n)}^c of
  * rqae/model.py:63-72 (rows of unit length, or plain), else 0; -1 if `packed` is no block.  Waits for `stream` -- the pack that
  * wrote the answer; the only call of this arm that blocks.  A caller that got n >= 2 may pass lean_levels = 5 below. */

@@ -45,6 +45,8 @@ SYMBOLS = (
     "rqae_hip_gram_packed_bytes",
     "rqae_hip_gram_pack",
     "rqae_hip_gram_lattice",
+    "rqae_hip_normalize_codebooks",
+    "rqae_hip_gram_repack_codebooks",
     "rqae_hip_gram_workspace_bytes",
     "rqae_hip_encode_gram",
     "rqae_hip_encode_gram_gemma_supported",
@@ -136,6 +138,10 @@ def lib():
     L.rqae_hip_gram_packed_bytes.restype = sz
     L.rqae_hip_gram_pack.argtypes = [vp, i, i, i, i, vp, vp, vp, vp, vp, i, vp, vp]
     L.rqae_hip_gram_pack.restype = i
+    L.rqae_hip_normalize_codebooks.argtypes = [vp, i, i, i, i, vp, vp]
+    L.rqae_hip_normalize_codebooks.restype = i
+    L.rqae_hip_gram_repack_codebooks.argtypes = [vp, i, i, i, i, vp, vp]
+    L.rqae_hip_gram_repack_codebooks.restype = i
     L.rqae_hip_gram_lattice.argtypes = [vp, vp]
     L.rqae_hip_gram_lattice.restype = i
     L.rqae_hip_gram_workspace_bytes.argtypes = [i, i, i, i, i64, i]
@@ -288,6 +294,30 @@ def gram_pack(w_in, b_in, codebook, w_out, b_out, codebook_shared: bool, in_scal
     if out.lattice_n < 0:
         _check(1, "rqae_hip_gram_lattice")
     return out
+
+
+def normalize_codebooks(codebook: torch.Tensor, levels: int) -> torch.Tensor:
+    """RQAE.normalize_codebooks as a ``levels``-level forward applies it (include/rqae_hip.h: rqae_hip_normalize_codebooks): ``codebook``
+    [L,K,c] fp32 is renormalised in place ``levels`` times; returns the per-level snapshots [L,K,c] (entries >= levels unspecified)."""
+    _require_cuda(codebook, "codebook")
+    if codebook.dtype != torch.float32 or not codebook.is_contiguous() or codebook.dim() != 3:
+        raise RuntimeError("normalize_codebooks: codebook must be contiguous float32 [L, K, c]")
+    L_, K, c = codebook.shape
+    used = torch.empty_like(codebook)
+    with torch.cuda.device(codebook.device):
+        rc = lib().rqae_hip_normalize_codebooks(codebook.data_ptr(), L_, K, c, int(levels), used.data_ptr(), _stream(codebook.device))
+    _check(rc, "rqae_hip_normalize_codebooks")
+    return used
+
+
+def gram_repack_codebooks(gpacked: torch.Tensor, dims, codebook_levels: torch.Tensor):
+    """The codebook part of a block packed with codebook_shared = False rebuilt from per-level rows [L,K,c] (in place, one launch)."""
+    d, c, K, L_ = dims
+    if codebook_levels.shape != (L_, K, c) or codebook_levels.dtype != torch.float32 or not codebook_levels.is_contiguous():
+        raise RuntimeError("gram_repack_codebooks: per-level rows must be contiguous float32 [L, K, c]")
+    with torch.cuda.device(gpacked.device):
+        rc = lib().rqae_hip_gram_repack_codebooks(gpacked.data_ptr(), d, c, K, L_, codebook_levels.data_ptr(), _stream(gpacked.device))
+    _check(rc, "rqae_hip_gram_repack_codebooks")
 
 
 def _gram_default_options(gpacked, options):

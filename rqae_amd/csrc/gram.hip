@@ -390,6 +390,58 @@ __global__ void gram_pack_bias_kernel(Geom g, const float *b_out, float *bias_pr
     }
 }
 
+// RQAE.normalize_codebooks as the level loop applies it (rqae/model.py:126-131, called once per level from quantize, :196): every row of
+// EVERY level is divided by its 2-norm once per level of the call -- `levels` times in all, in place -- and level l is quantised
+// against its rows as they stand after l + 1 of them (renormalising a unit row is not a bit-wise no-op until it reaches a fixed
+// point, usually after one or two steps).  Rows are independent, so one thread takes one row through all `levels` steps: torch-CPU's
+// order of the 2-norm (oracle/rqae_oracle.c: aten_norm2 -- groups of 8 as fma lanes, one group of 4 as rounded squares, an fma tail),
+// IEEE square root and divisions: the reference's bits.  used[l] (l < levels) receives level l's snapshot; cb the final state.
+__global__ void normalize_codebooks_kernel(float *cb, int L, int K, int c, int levels, float *used)
+{
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (long long)L * K) return;
+    const int lam = (int)(row / K);
+    float v[16], snap[16];
+    for (int j = 0; j < 16; ++j) { v[j] = j < c ? cb[row * c + j] : 0.0f; snap[j] = v[j]; }
+    bool snapped = false;
+    for (int t = 1; t <= levels; ++t) {
+        float acc = 0.0f;
+        int dd = 0;
+        if (c >= 8) {
+            float buf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int d0 = 0; d0 + 8 <= c; d0 += 8) {
+                for (int j = 0; j < 8; ++j) buf[j] = __builtin_fmaf(v[d0 + j], v[d0 + j], buf[j]);
+                dd = d0 + 8;
+            }
+            acc = buf[0];
+            for (int j = 1; j < 8; ++j) acc = acc + buf[j];
+        }
+        if (c - dd >= 4) {
+            for (int j = 0; j < 4; ++j) { const float sq = v[dd + j] * v[dd + j]; acc = acc + sq; }
+            dd += 4;
+        }
+        for (; dd < c; ++dd) acc = __builtin_fmaf(v[dd], v[dd], acc);
+        const float nrm = __builtin_sqrtf(acc);
+        bool same = true;
+        for (int j = 0; j < 16; ++j)
+            if (j < c) {
+                const float nv = v[j] / nrm;
+                same = same && (__builtin_bit_cast(unsigned, nv) == __builtin_bit_cast(unsigned, v[j]));
+                v[j] = nv;
+            }
+        if (t == lam + 1) {
+            for (int j = 0; j < 16; ++j) snap[j] = v[j];
+            snapped = true;
+        }
+        if (same) break;      // a fixed point: every further step leaves the row as it is
+    }
+    if (!snapped)
+        for (int j = 0; j < 16; ++j) snap[j] = v[j];      // the fixed point was reached before step lam + 1 (or lam >= levels: unused)
+    for (int j = 0; j < c; ++j) cb[row * c + j] = v[j];
+    if (used)      // (levels past the call's depth: their final rows -- unused by the call, but never uninitialised memory)
+        for (int j = 0; j < c; ++j) used[row * c + j] = lam < levels ? snap[j] : v[j];
+}
+
 // ------------------------------------------------------------------------------------------------ kernel A: project
 struct ProjParams {
     const void *x;
@@ -1541,6 +1593,34 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
         if (int rc = rqae_d3::pack_g3(b + lo.g3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, g3_maxbits)), reinterpret_cast<const float *>(b + lo.gneg), L, g.GB, s)) return rc;
     // ... and of W_in (gram_proj3.hpp), in_scale folded in like the bf16 image's
     if (int rc = rqae_p3::pack(b + lo.win3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, win_maxbits)), d, c, L, g.CP, g.GL, g.GP, g.NOG, w_in, in_scale, s)) return rc;
+    return 0;
+}
+
+// RQAE.normalize_codebooks through a `levels`-level forward call (rqae/model.py:126-131,196): codebook [L][K][c] is renormalised
+// `levels` times in place, used_out [L][K][c] (or NULL) receives for every level l < levels its rows after l + 1 renormalisations
+// (what quantize sees at that level); torch-CPU's arithmetic order: the reference's bits.
+int rqae_hip_normalize_codebooks(float *codebook, int L, int K, int c, int levels, float *used_out, void *stream)
+{
+    if (!codebook || L < 1 || K < 1 || c < 1 || c > 16 || levels < 0 || levels > L) return gfail("normalize_codebooks: bad arguments (L=%d K=%d c=%d levels=%d)", L, K, c, levels);
+    if (levels == 0) return 0;
+    const long long rows = (long long)L * K;
+    hipLaunchKernelGGL(normalize_codebooks_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), codebook, L, K, c, levels, used_out);
+    G_TRY(hipGetLastError());
+    return 0;
+}
+
+// The codebook part of a block packed with codebook_shared = 0 built again from codebook [L][K][c] (the per-level snapshots of one
+// call): the bf16-piece images and the fp32 rows; everything else in the block (the linear maps' images, Gram blocks) stays.
+int rqae_hip_gram_repack_codebooks(void *packed, int d, int c, int K, int L, const float *codebook, void *stream)
+{
+    if (!packed || !codebook) return gfail("gram_repack_codebooks: null pointer");
+    if (!rqae_hip_gram_supported(d, c, K, L, 0)) return gfail("gram_repack_codebooks: unsupported shape d=%d c=%d K=%d L=%d", d, c, K, L);
+    const Geom g = make_geom(d, c, K, L, 0);
+    const GLayout lo = make_glayout(g);
+    char *b = static_cast<char *>(packed);
+    hipLaunchKernelGGL(gram_pack_cb_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), g, codebook, reinterpret_cast<uint16_t *>(b + lo.cb_img),
+                       reinterpret_cast<float *>(b + lo.cb_f32));
+    G_TRY(hipGetLastError());
     return 0;
 }
 

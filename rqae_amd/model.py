@@ -277,12 +277,21 @@ class RQAE(nn.Module):
         if self.quantization_method in _FSQ_METHODS:
             return self.packed_weights()
         with torch.no_grad():
-            used = self.codebook.data.clone()
-            for l in range(levels):
-                self.normalize_codebooks()
-                used[l] = self.codebook.data[l]
-            self.__dict__["_codebook_used"] = used[:levels].clone()
+            used = self._renormalise_for_call(levels)
             return self._pack(used)
+
+    def _renormalise_for_call(self, levels: int) -> torch.Tensor:
+        """The in-place renormalisations of one ``levels``-level call (rqae/model.py:196 -> 126-131) as ONE kernel
+        (rqae_hip_normalize_codebooks: every row through its ``levels`` steps, torch-CPU's arithmetic order -- the reference's bits):
+        ``self.codebook`` ends as the reference leaves it, the returned [L,K,c] tensor holds what each level < levels is quantised
+        against (kept in ``_codebook_used`` for inspection)."""
+        cb = self.codebook.data
+        if cb.dtype != torch.float32 or not cb.is_contiguous():
+            raise RuntimeError("rqae_amd: the codebook parameter must be contiguous float32")
+        used = _native.normalize_codebooks(cb, levels)
+        self.__dict__["_codebook_used"] = used[:levels]
+        self._packed = None  # the parameter moved under the cached exact-arm block (.data writes bump no version counter)
+        return used
 
     # ------------------------------------------------------------ matrix-core arm
     def _use_gram(self, n_tokens: int, levels: int, want_recon: bool = True) -> bool:
@@ -350,18 +359,18 @@ class RQAE(nn.Module):
         if self.quantization_method in _FSQ_METHODS:
             return self.gram_packed_weights(), True
         with torch.no_grad():
-            used = self.codebook.data.detach().float().clone()
-            for l in range(levels):
-                self.normalize_codebooks()
-                used[l] = self.codebook.data[l]
-            self.__dict__["_codebook_used"] = used[:levels].clone()
+            used = self._renormalise_for_call(levels)
             key = self._weights_key()
             ent = self.__dict__.get("_gram_free")
-            if ent is None or ent[0] != key or ent[1].shape != used.shape or not torch.equal(ent[1], used):
-                if not torch.isfinite(used).all():
+            if ent is None or ent[0] != key:
+                # the linear maps' images and the Gram blocks: once per parameter state
+                if not torch.isfinite(used[:levels]).all():
                     raise RuntimeError("rqae_amd: codebook contains non-finite values")
                 w_in, b_in, w_out, b_out = self._stacked()
-                ent = self.__dict__["_gram_free"] = (key, used, _native.gram_pack(w_in, b_in, used.contiguous(), w_out, b_out, False))
+                ent = self.__dict__["_gram_free"] = (key, None, _native.gram_pack(w_in, b_in, used, w_out, b_out, False))
+            else:
+                # ... the codebook part again at every call, on the device (one launch, no comparison on the host)
+                _native.gram_repack_codebooks(ent[2], self._dims(), used)
         return ent[2], False
 
     # ------------------------------------------------------------- small mirrors

@@ -112,8 +112,9 @@ def test_generic_shape_free_codebook():
     q, idx = run_forward(m, x)
     assert np.array_equal(idx, g["codes"].astype(np.int64))
     assert rel_err(q[g["rows"]], g["q_rows"]) < RTOL
-    used = m._codebook_used.cpu().numpy()        # what each level really saw on this device
-    assert rel_err(used, g["codebook_used"]) < 1e-6
+    used = m._codebook_used.cpu().numpy()        # what each level really saw: rqae_hip_normalize_codebooks, one launch per call
+    assert np.array_equal(used, g["codebook_used"])                                  # the reference's bits (torch-CPU's order of the row norm)
+    assert np.array_equal(m.codebook.detach().cpu().numpy(), g["codebook_after"])   # ... and the parameter as the reference leaves it
     q_o, idx_o = oracle.forward(x, dict(w, codebook=used))
     assert np.array_equal(idx, idx_o) and np.array_equal(q, q_o)
     # decode afterwards uses codebook[0] of the drifted parameter (model.py:234)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time guard: no compiler-generated packed fp32 arithmetic in the matrix-core arm's level chains or the search kernels.
+"""Build-time guard: no compiler-generated packed fp32 arithmetic in ANY kernel of the matrix-core arm's units or the search kernels.
 
     python tools/isa_guard.py rqae_amd/csrc/gram.o rqae_amd/csrc/search.o
 
@@ -17,7 +17,7 @@ import sys
 import tempfile
 
 LLVM = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
-GUARDED = re.compile(r"gram_levels|gram_fused_kernel|search_")
+GUARDED = re.compile(r".")      # every kernel of the objects named on the command line (the matrix-core arm's units and the search)
 PACKED = re.compile(r"\bv_pk_(fma|mul|add)_f32\b")
 
 

@@ -25,7 +25,8 @@ def short(k):
 def main():
     src = sys.argv[1]
     j = json.load(open(src))
-    ks = {k: v for k, v in j["kernels"].items() if any(t in k for t in ("gram_fused_kernel", "gram_levels", "gram_project", "gram_reconstruct"))}
+    ks = {k: v for k, v in j["kernels"].items() if any(t in k for t in ("gram_fused_kernel", "gram_levels", "gram_proj", "gram_recon", "deep_"))}
+    configs = "--configs" in sys.argv      # the pass over bench.py's `configs` block: a per-kernel summary only (no C2 traffic file)
     rd = sum(v.get("hbm_read_bytes", 0.0) for v in ks.values())
     wr = sum(v.get("hbm_write_bytes", 0.0) for v in ks.values())
     tokens = 262144
@@ -35,8 +36,9 @@ def main():
                           for k, v in ks.items()},
            "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --no-cpu-baseline --no-extra-legs --no-parity --spinup-ms 0 --steps 4 --warmup 2` by tools/pmc.py; "
                    "KiB x 1024, reads x 2 (gfx950 counts 128-byte requests of 16-byte-per-lane streams at 64 bytes).  Above the algorithmic bytes by the "
-                   "intermediates of the three-kernel path (projections 50 MB written + read, fp32 straight-through values 42 MB written + read) and the weight images' first touch."}
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_traffic.json"), "w"), indent=1)
+                   "intermediates of the three-kernel path (projections written + read, fp32 straight-through values written + read) and the weight images' first touch."}
+    if not configs:
+        json.dump(out, open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_traffic.json"), "w"), indent=1)
     summ = {}
     for k, v in ks.items():
         name = short(k)
@@ -44,10 +46,15 @@ def main():
         ns = v.get("mean_ns_by_pass", {})
         if ns:
             summ[name]["mean_kernel_ns"] = sum(ns.values()) / len(ns)
+        if "hbm_read_bytes" in v or "hbm_write_bytes" in v:
+            summ[name]["hbm_bytes"] = v.get("hbm_read_bytes", 0.0) + v.get("hbm_write_bytes", 0.0)
+            if ns:
+                summ[name]["hbm_TBs"] = summ[name]["hbm_bytes"] / (sum(ns.values()) / len(ns)) / 1e3
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
             # busy cycles summed over the 1024 SIMDs against the kernel's shader cycles (GRBM_GUI_ACTIVE sums 8 XCDs)
             summ[name]["mfma_busy_frac"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
-    json.dump({"command": j["command"], "passes": j["passes"], "kernels": summ}, open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    json.dump({"command": j["command"], "passes": j["passes"], "sources_sha256_16": bench.sources_hash(), "kernels": summ},
+              open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_pmc_{'configs' if configs else 'summary'}.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: out[k] for k in ("hbm_bytes_per_step", "algorithmic_bytes_per_step", "sources_sha256_16")}))
     for n, v in summ.items():
         print(n, "mfma_busy_frac", round(v.get("mfma_busy_frac", 0), 3), "ms", round(v.get("mean_kernel_ns", 0) / 1e6, 4))

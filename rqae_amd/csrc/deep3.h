@@ -23,7 +23,8 @@ struct Gemm {
     const void *wimg;            // pack_g3()'s image, or rqae_r3's W_out image
     const unsigned *maxbits;     // that image's scale word
     long long n_tokens, tok_pad;
-    int KSA, KSW, nks;           // k-steps per tile in the two images; k-steps [0, nks) are multiplied
+    int KSA, KSW;                // k-steps per tile in the two images
+    int ks0, nks;                // k-steps [ks0, ks0 + nks) are multiplied
     int nt0, ntiles;             // output tiles of 32 columns: nt0 .. nt0 + ntiles - 1 (ntiles % 4 == 0)
     float *P;                    // corrections: added into [groups][tok_pad][16]
     const float *bias;           // reconstruction: [d] and out [n_tokens][d]

@@ -67,7 +67,7 @@ static int launch(int mode, const Gemm &g, int ncu, hipStream_t s)
     if (g.ntiles % D3_NTB || g.nks < 1) return d3fail("deep gemm: %d output tiles, %d k-steps", g.ntiles, g.nks);
     Deep3Params p;
     p.apieces = static_cast<const uint16_t *>(g.apieces); p.wimg = static_cast<const uint16_t *>(g.wimg); p.maxbits = g.maxbits;
-    p.P = g.P; p.bias = g.bias; p.out = g.out; p.n_tokens = g.n_tokens; p.tok_pad = g.tok_pad; p.KSA = g.KSA; p.KSW = g.KSW; p.nks = g.nks;
+    p.P = g.P; p.bias = g.bias; p.out = g.out; p.n_tokens = g.n_tokens; p.tok_pad = g.tok_pad; p.KSA = g.KSA; p.KSW = g.KSW; p.ks0 = g.ks0; p.nks = g.nks;
     p.nt0 = g.nt0; p.npass = g.ntiles / D3_NTB; p.d = g.d;
     const long long items = ((g.n_tokens + D3_TILE - 1) / D3_TILE) * p.npass;
     long long nb = items < ncu ? items : ncu;

@@ -1728,11 +1728,19 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             if (int rc = rqae_p3::launch(ap, ncu, s)) return rc;
             if (mark) G_TRY(hipEventRecord(ev[1], s));
             for (int b = 0; b < nblocks; ++b) {
-                if (b > 0) {
-                    // the block's 128 projection columns see every level before it: P[:, block] += CV[:, < 128 b] x G
+                // Corrections, two-level (the straight-through values' fragments are 4 bytes per value and token: left-looking over ALL
+                // earlier levels reads 262 KB of them per token at L = 1024 -- 34 GB per 131072 tokens, 8 ms of HBM time -- so):
+                //   * across SUPER-blocks of 8 blocks (256 levels) right-looking: when a super-block is done, ONE product adds its
+                //     1024 values' contribution to every later column (4 KB of fragments per token, re-read per pass from the
+                //     Infinity Cache; the columns are read and written once per super-block);
+                //   * inside a super-block left-looking as before: the block's 128 columns see the super-block's earlier blocks.
+                constexpr int SBK = 8;                                   // blocks per super-block
+                const int sb0 = (b / SBK) * SBK;                        // first block of this block's super-block
+                if (b > sb0) {
                     rqae_d3::Gemm gm;
                     gm.apieces = pieces; gm.wimg = v.g3_img; gm.maxbits = v.g3_maxbits; gm.n_tokens = nt; gm.tok_pad = dtp; gm.KSA = KSall; gm.KSW = KSall;
-                    gm.nks = b * (BL * 4 / 16); gm.nt0 = b * (BL * 4 / 32); gm.ntiles = BL * 4 / 32; gm.P = dP; gm.bias = nullptr; gm.out = nullptr; gm.d = d;
+                    gm.ks0 = sb0 * (BL * 4 / 16); gm.nks = (b - sb0) * (BL * 4 / 16); gm.nt0 = b * (BL * 4 / 32); gm.ntiles = BL * 4 / 32;
+                    gm.P = dP; gm.bias = nullptr; gm.out = nullptr; gm.d = d;
                     if (int rc = rqae_d3::corrections(gm, ncu, s)) return rc;
                 }
                 // the lattice form of the level chain on the block's 32 levels (four level groups: corrections between them through P)
@@ -1750,12 +1758,20 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                 G_TRY(hipGetLastError());
                 if (q_out || b + 1 < nblocks)
                     if (int rc = rqae_d3::convert(planes, dtp, BL, b * BL, pieces, L, s)) return rc;
+                if ((b + 1) % SBK == 0 && b + 1 < nblocks) {
+                    // the super-block that just ended, onto every later column of the call
+                    rqae_d3::Gemm gm;
+                    gm.apieces = pieces; gm.wimg = v.g3_img; gm.maxbits = v.g3_maxbits; gm.n_tokens = nt; gm.tok_pad = dtp; gm.KSA = KSall; gm.KSW = KSall;
+                    gm.ks0 = sb0 * (BL * 4 / 16); gm.nks = SBK * (BL * 4 / 16); gm.nt0 = (b + 1) * (BL * 4 / 32); gm.ntiles = (nblocks - (b + 1)) * (BL * 4 / 32);
+                    gm.P = dP; gm.bias = nullptr; gm.out = nullptr; gm.d = d;
+                    if (int rc = rqae_d3::corrections(gm, ncu, s)) return rc;
+                }
             }
             if (mark) G_TRY(hipEventRecord(ev[2], s));
             if (q_out) {
                 rqae_d3::Gemm gm;
                 gm.apieces = pieces; gm.wimg = v.wout3_img; gm.maxbits = v.wout_maxbits; gm.n_tokens = nt; gm.tok_pad = dtp; gm.KSA = KSall; gm.KSW = g.KS3;
-                gm.nks = levels * 4 / 16; gm.nt0 = 0; gm.ntiles = d / 32; gm.P = nullptr; gm.bias = v.bias_prefix + (size_t)(levels - 1) * d;
+                gm.ks0 = 0; gm.nks = levels * 4 / 16; gm.nt0 = 0; gm.ntiles = d / 32; gm.P = nullptr; gm.bias = v.bias_prefix + (size_t)(levels - 1) * d;
                 gm.out = q_out + (size_t)t0 * d; gm.d = d;
                 if (int rc = rqae_d3::reconstruct(gm, ncu, s)) return rc;
             }

@@ -93,7 +93,7 @@ struct Deep3Params {
     float *out;                  // MODE 1: [n_tokens][d]
     long long n_tokens, tok_pad;
     int KSA, KSW;                // k-steps per tile in the two images
-    int nks;                     // k-steps of this product: [0, nks)
+    int ks0, nks;                // k-steps of this product: [ks0, ks0 + nks)
     int nt0, npass;              // first output tile, passes of D3_NTB tiles
     int d;                       // MODE 1: row length of out
 };
@@ -118,11 +118,14 @@ __global__ __launch_bounds__(D3_NW * 64) void deep_gemm_kernel(Deep3Params p)
     }
     const int nch = (p.nks + D3_KC - 1) / D3_KC;
     const long long ntile = (p.n_tokens + D3_TILE - 1) / D3_TILE;
-    // work items = (token tile, pass); a workgroup walks them with the token tile fastest-varying across workgroups
+    // work items = (token tile, pass), the PASS fastest-varying: the workgroups in flight at any moment share a few token tiles, so a
+    // tile's operand fragments (16 KB per token at L = 1024) come from HBM once and from the Infinity Cache for its other passes --
+    // with the tile fastest-varying every pass re-read all of them from HBM (18 x 2.1 GB per 131072 tokens: the reconstruction ran
+    // at the speed of those reads, 8.9 ms)
     const long long nitem = ntile * p.npass;
     for (long long item = blockIdx.x; item < nitem; item += gridDim.x) {
-        const long long tile = item % ntile;
-        const int pass = (int)(item / ntile);
+        const long long tile = item / p.npass;
+        const int pass = (int)(item - tile * p.npass);
         const long long tile0 = tile * D3_TILE;
         const long long tile_end = tile0 + D3_TILE < p.n_tokens ? tile0 + D3_TILE : p.n_tokens;
         const long long tw0 = tile0 + (long long)wave * 32;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(D3_NW * 64) void deep_gemm_kernel(Deep3Params p)
             for (int q = wave; q < D3_NTB * D3_KC * 2; q += D3_NW) {
                 const int k = q / (D3_NTB * 2), rem = q - k * (D3_NTB * 2);
                 int ks = ch * D3_KC + k;
-                ks = ks < p.nks ? ks : p.nks - 1;
+                ks = p.ks0 + (ks < p.nks ? ks : p.nks - 1);
                 dma_piece(uniform_ptr(p.wimg + (((size_t)(nt_first + (rem >> 1)) * p.KSW + ks) * 2 + (rem & 1)) * 512), lds0 + buf * D3_STAGE + q * 1024, lane16);
             }
         };
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(D3_NW * 64) void deep_gemm_kernel(Deep3Params p)
             for (int k = 0; k < D3_KC; ++k) {
                 int ks = ch * D3_KC + k;
                 const bool live = ks < p.nks;
-                ks = live ? ks : p.nks - 1;
+                ks = p.ks0 + (live ? ks : p.nks - 1);
                 const uint16_t *src = p.apieces + (((size_t)t32 * p.KSA + ks) * 2) * 512 + lane * 8;
                 A[k][0] = *reinterpret_cast<const u32x4 *>(src);
                 A[k][1] = *reinterpret_cast<const u32x4 *>(src + 512);
@@ -177,6 +180,16 @@ __global__ __launch_bounds__(D3_NW * 64) void deep_gemm_kernel(Deep3Params p)
                     acc[o] = mfma32(wh, A[k][1], acc[o]);
                     acc[o] = mfma32(wl, A[k][0], acc[o]);
                 }
+            // "all reads, then all MFMAs" put in order: two fragment pairs ahead, then a pair's reads behind each pair's three matrix
+            // instructions (left alone hipcc reads a pair, waits out the LDS latency, multiplies: 16 exposed latencies per chunk)
+            constexpr int NPAIR = D3_KC * D3_NTB, PFP = 2;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PFP, 0);
+#pragma unroll
+            for (int i = 0; i < NPAIR - PFP; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * PFP, 0);
         };
         __syncthreads();              // every wave has left the item before (its stage reads, its transposition buffer)
         issue_w(0, 0);

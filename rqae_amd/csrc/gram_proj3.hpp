@@ -236,6 +236,18 @@ __global__ __launch_bounds__(P3_NW * 64) void gram_proj3_kernel(Proj3Params p)
                             if constexpr (NP == 2) acc[o] = mfma32(wh, bl, acc[o]);
                         }
                     }
+                    // the stage's fragment pairs put in order: the x fragments and two W pairs ahead, then a pair's reads behind each
+                    // pair's matrix instructions (left alone hipcc reads a pair, waits out the LDS latency, multiplies)
+                    if constexpr (!NORM && XT != RQAE_X_BF16 && XT != RQAE_X_F32) {
+                        constexpr int NPAIR = KW * OT, PFP = NPAIR < 2 ? NPAIR : 2, MPP = NP == 2 ? 3 : 2;
+                        __builtin_amdgcn_sched_group_barrier(0x100, KW * NP + 2 * PFP, 0);
+#pragma unroll
+                        for (int i = 0; i < NPAIR - PFP; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, MPP, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, MPP * PFP, 0);
+                    }
                 }
                 wslot = wslot == 2 ? 0 : wslot + 1;
                 if (WS == WPX - 1) xslot = NXS == 3 ? (xslot == 2 ? 0 : xslot + 1) : (xslot ^ 1);

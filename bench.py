@@ -64,7 +64,7 @@ GRAM_MFMA_FLOPS_PER_TOKEN = 2 * D * 64 * 2 + 2 * D * 48 * 3
 
 PROFILE_ROUND = "r04"     # profiles/<round>_traffic.json, <round>_pmc_summary.json: the committed counter passes of this round
 
-KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "gram_wide.hpp", "gram_recon3.hpp", "gram_small.hpp", "gram_pieces.hpp", "recon3.hip", "gram_proj3.hpp", "proj3.hip", "gram_deep3.hpp", "deep3.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
+KERNEL_SOURCES = ["gram.hip", "gram_fused.hpp", "gram_stream.hpp", "gram_wide.hpp", "gram_recon3.hpp", "gram_small.hpp", "gram_pieces.hpp", "recon3.hip", "gram_proj3.hpp", "proj3.hip", "gram_deep3.hpp", "deep3.hip", "gram_sign3.hpp", "sign3.hip", "rqae_hip.hip", "encode_main.hip", "encode_lds.hpp", "rqae_common.hpp"]
 
 
 def sources_hash():
@@ -215,7 +215,9 @@ def issued_mfma_flops_per_token(d, c, K, L, dtype, lattice):
         full, rem = divmod(L, gl)
         gs = (6 * cp * gl + 31) // 32 * 32
         recon = 2 * d * (full * gs + (6 * cp * rem + 31) // 32 * 32)
-    return proj + scan + recon
+    # the level chain of a two-point lattice at C4's shape (gram_sign3.hpp): 68 (level, later column tile) pairs x 3 products of 32 x 32 x 16
+    chain = 68 * 3 * 2 * 32 * 16 if (lattice and c == 13 and K == 2 ** 13 and L == 16) else 0
+    return proj + scan + recon + chain
 
 
 def config_leg(np, torch, device, name, cfg_name, tokens, dtype, what, steps=10, warmup=3, n_check=4096, options=None,

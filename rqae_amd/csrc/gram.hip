@@ -35,6 +35,7 @@
 #include "recon3.h"
 #include "proj3.h"
 #include "deep3.h"
+#include "sign3.h"
 
 extern __attribute__((visibility("hidden"))) __thread char rqae_g_err[512];   // __thread, not thread_local: no TLS init wrapper (a hidden weak _ZTH call crashes)
 
@@ -115,7 +116,7 @@ __host__ __device__ inline int nks_recon(const Geom &g, int levels)
 inline bool deep_block_ok(const Geom &g) { return g.L > GRAM_DEEP_L && g.c == 4 && g.L % 64 == 0 && g.shared_cb && (size_t)g.K * g.c * 4 <= 150 * 1024 && g.d % 128 == 0; }
 
 struct GLayout {
-    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, wout3_img, win3_img, g3_img, total;
+    size_t win_img, kconst, gneg, cb_img, cb_f32, wout_img, bias_prefix, wout3_img, win3_img, g3_img, sign_img, total;
 };
 
 GLayout make_glayout(const Geom &g)
@@ -133,6 +134,7 @@ GLayout make_glayout(const Geom &g)
     lo.wout3_img = off;   off += al256(rqae_r3::image_bytes(g.d, g.c, g.L));                              // fp16 two-piece W_out image (gram_recon3.hpp)
     lo.win3_img = off;    off += al256(rqae_p3::image_bytes(g.d, g.NOG));                                   // fp16 two-piece W_in image (gram_proj3.hpp)
     lo.g3_img = off;      off += deep_block_ok(g) ? al256(rqae_d3::g3_bytes(g.L)) : 0;                              // fp16 two-piece image of -(W_in W_out) (gram_deep3.hpp)
+    lo.sign_img = off;    off += al256(rqae_s3::image_bytes(g.c, g.L));                                        // Gram blocks as the sign chain multiplies them (gram_sign3.hpp: c = 13, depth 16)
     lo.total = off;
     return lo;
 }
@@ -144,7 +146,9 @@ struct GHeader {
     unsigned wout_maxbits;    // bits of max |W_out| (gram_pack_absmax_kernel): fixes the power-of-two scale of the fp16 image
     unsigned win_maxbits;     // the same for W_in (x in_scale)
     unsigned g3_maxbits;      // the same for the Gram blocks (gram_deep3.hpp)
-    int pad[52];
+    unsigned sign_maxbits;    // ... and for the sign chain's image of them (gram_sign3.hpp)
+    int sign_exact;           // 1: every codebook row is exactly (+-mag)^c -- the sign chain may run
+    int pad[50];
 };
 static_assert(sizeof(GHeader) == 256, "header");
 
@@ -804,6 +808,7 @@ struct LevParams {
     int levels, L, K, KTP, c, shared_cb;
     int idx_stride;           // row length of idx (= levels, but for a block of a deeper call: gram_deep3.hpp)
     const int *lat_flag;      // the block's lattice word (GHeader::lattice_n: n >= 2 when the codebook is an FSQ lattice), or NULL
+    const int *sign_flag = nullptr;     // GHeader::sign_exact when the sign chain (gram_sign3.hpp) was launched ahead of this kernel, or NULL: it ran if the word is 1 and the lattice has two points
 };
 
 // One wave = 64 tokens, one token per lane for everything in c-space; for the cosine contraction the wave's
@@ -1383,9 +1388,10 @@ int device_cus()
 
 struct GView {
     Geom g;
-    const uint16_t *win_img, *cb_img, *wout_img, *wout3_img, *win3_img, *g3_img;
+    const uint16_t *win_img, *cb_img, *wout_img, *wout3_img, *win3_img, *g3_img, *sign_img;
     const float *kconst, *gneg, *cb_f32, *bias_prefix;
-    const unsigned *wout_maxbits, *win_maxbits, *g3_maxbits;
+    const unsigned *wout_maxbits, *win_maxbits, *g3_maxbits, *sign_maxbits;
+    const int *sign_exact;
 };
 
 // the header lives on the device; the caller passes (d, c, K, L) again and the geometry is recomputed
@@ -1408,6 +1414,9 @@ GView gview(const void *packed, int d, int c, int K, int L, int shared_cb)
     v.win_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, win_maxbits));
     v.g3_img = reinterpret_cast<const uint16_t *>(b + lo.g3_img);
     v.g3_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, g3_maxbits));
+    v.sign_img = reinterpret_cast<const uint16_t *>(b + lo.sign_img);
+    v.sign_maxbits = reinterpret_cast<const unsigned *>(b + offsetof(GHeader, sign_maxbits));
+    v.sign_exact = reinterpret_cast<const int *>(b + offsetof(GHeader, sign_exact));
     return v;
 }
 
@@ -1591,6 +1600,10 @@ int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_
     // ... of the Gram blocks for the cross-block corrections of deep calls (gram_deep3.hpp)
     if (deep_block_ok(g))
         if (int rc = rqae_d3::pack_g3(b + lo.g3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, g3_maxbits)), reinterpret_cast<const float *>(b + lo.gneg), L, g.GB, s)) return rc;
+    // ... for the level chain of a two-point lattice (gram_sign3.hpp)
+    if (rqae_s3::supported(c, L, g.shared_cb))
+        if (int rc = rqae_s3::pack(b + lo.sign_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, sign_maxbits)), reinterpret_cast<int *>(b + offsetof(GHeader, sign_exact)),
+                                   reinterpret_cast<const float *>(b + lo.gneg), codebook, c, L, K, g.GB, s)) return rc;
     // ... and of W_in (gram_proj3.hpp), in_scale folded in like the bf16 image's
     if (int rc = rqae_p3::pack(b + lo.win3_img, reinterpret_cast<unsigned *>(b + offsetof(GHeader, win_maxbits)), d, c, L, g.CP, g.GL, g.GP, g.NOG, w_in, in_scale, s)) return rc;
     return 0;
@@ -1966,6 +1979,15 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                 G_TRY(hipGetLastError());
                 return 0;
             };
+            // a two-point lattice at C4's shape: the chain as small matrix products (gram_sign3.hpp), ahead of the lattice form, which
+            // returns when that kernel ran (the block's sign_exact word and lattice_n == 2, both read on the device)
+            if (wide && tuning().recon == 3 && levels == L && rqae_s3::supported(c, L, g.shared_cb)) {
+                rqae_s3::Args sa;
+                sa.P = P; sa.kconst = v.kconst; sa.img = v.sign_img; sa.maxbits = v.sign_maxbits; sa.lat_flag = lat; sa.exact_flag = v.sign_exact; sa.cb = v.cb_f32;
+                sa.planes = reinterpret_cast<float *>(cvimg); sa.idx = pl.idx; sa.n_tokens = nt; sa.tok_pad = tp; sa.c = c; sa.L = L; sa.K = K; sa.idx_stride = levels;
+                if (int rc = rqae_s3::launch(sa, ncu, s)) return rc;
+                pl.sign_flag = v.sign_exact;
+            }
             const bool multi = levels > g.GL;
             int rc;
             const bool ceq = c == g.CP;       // no padded coordinate: the common case, with c a compile-time fact

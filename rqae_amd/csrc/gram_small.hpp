@@ -55,3 +55,17 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// An LDS read the compiler does not schedule (16 bytes per lane at addr + OFF) and the counted wait that hands its result on: LDS
+// returns in order, so "at most NEWER reads outstanding" means everything issued before the NEWER newest has arrived.  The wait
+// takes the registers as operands -- whatever consumes them stays behind it.  (Left to itself hipcc reads an operand pair, waits out
+// the LDS latency and multiplies; sched_group_barrier pipelines do not survive other vector work in the loop.)
+template <int OFF>
+__device__ __forceinline__ void lds_read16(u32x4 &dst, unsigned addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int NEWER>
+__device__ __forceinline__ void lds_wait_pair(u32x4 &a, u32x4 &b)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(NEWER));
+}

@@ -229,6 +229,7 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
     //  per-lane value hipcc turns its loops into exec-masked ones)
     const int nlat = p.lat_flag ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int *>(p.lat_flag)) : 0;
     if (LAT ? nlat < 2 : nlat >= 2) return;
+    if (LAT && nlat == 2 && p.sign_flag && __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int *>(p.sign_flag)) == 1) return;      // the sign chain ran (gram_sign3.hpp)
     using G = WideGeom<CP>;
     constexpr int GL = G::GL, GP = G::GP, NKC = G::NKC, GB = G::GB, STAGE = G::STAGE, CVS = G::CVS;
     static_assert(NKC == 1 || NKC == 3, "one or three k-steps per cosine contraction");

@@ -472,6 +472,46 @@ def test_gram_c4_wide_codebook_depth_16():
     print(f"gram arm, C4 depth 16, {n} tokens: {len(rows)} low-margin tokens differ from the exact arm, all adjudicated")
 
 
+def test_sign_chain_and_its_fallback():
+    """csrc/gram_sign3.hpp: at BASELINE configs[3]'s shape (c 13, K 2^13, depth 16, every level run) the level chain of the two-point
+    lattice runs as small matrix products.  Against the oracle (Tier 2) at ragged sizes; against the lattice form it replaces (the
+    per-call option recon = 1 keeps round 3's kernels: same projection, fp32 Gram updates) -- same codes but for low-margin tokens; NaN
+    / inf rows take row 0 at every level (rqae/model.py:182,188) and leave their neighbours alone; a codebook whose rows are not
+    EXACTLY (+-mag)^c (one value moved by an ulp: still a lattice to the pack's 1e-6) takes the lattice form, bit for bit."""
+    cfg = dict(synth.CONFIGS["C4"])
+    w = synth.weights(91, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    m_old = make_model(cfg, w, "gram")
+    m_old.gram_options = _native.gram_options(recon=1)
+    x = synth.activations(92, 1031, cfg["dim"])
+    for nn in (1, 31, 33, 255, 257, 1031):
+        q, idx, xs = run(m, x[:nn], torch.float32)
+        listed = check_tier2(xs, w, q, idx)
+        _, idx_old, _ = run(m_old, x[:nn], torch.float32)
+        assert ((idx != idx_old).any(axis=1)).sum() <= listed + 2
+    # non-finite rows
+    x2 = x[:300].copy()
+    x2[17] = np.nan
+    x2[64, 5] = np.inf
+    x2[257] = -np.inf
+    q, idx, _ = run(m, x2, torch.float32)
+    keep = np.ones(300, bool); keep[[17, 64, 257]] = False
+    _, idx_c, _ = run(m, x[:300], torch.float32)
+    assert np.array_equal(idx[keep], idx_c[keep]) and np.isfinite(q[keep]).all()
+    assert (idx[[17, 64, 257]] == 0).all() and np.isnan(q[[17, 64, 257]]).all()
+    # a codebook off by one ulp in one place: exact = 0, the lattice form runs -- the same kernel the option selects, so the same codes
+    w2 = {k: v.copy() for k, v in w.items()}
+    cb = w2["codebook"]
+    cb[..., 4097, 3] = np.nextafter(cb[..., 4097, 3], np.float32(2.0))
+    m2 = make_model(cfg, w2, "gram")
+    m2_old = make_model(cfg, w2, "gram")
+    m2_old.gram_options = _native.gram_options(recon=1)
+    _, idx2, xs = run(m2, x[:700], torch.float32)
+    _, idx2_old, _ = run(m2_old, x[:700], torch.float32)
+    assert np.array_equal(idx2, idx2_old)
+    check_tier2(xs, w2, None, idx2)
+
+
 def test_gram_decode_matches_the_exact_decode():
     """RQAE.decode on the matrix-core arm (rqae_hip_decode_gram: the reconstruction kernel fed by the codes) against the exact
     arm's decode, which is the oracle's and the reference capture's bits (test_hip_parity.py::test_decode): within 1e-6 of the

@@ -37,7 +37,13 @@ inline int r3_ks_template(int ks)
 }
 // element tiles per ring stage: stages of 16-32 KiB (three of them beside 36 KiB of wave buffers and the bias sums)
 __host__ __device__ constexpr int r3_group(int KS) { return KS <= 4 ? 4 : KS <= 8 ? 2 : 1; }
-__host__ __device__ inline size_t r3_lds_bytes(int d, int KS) { return pad1k((size_t)d * 4) + 3 * (size_t)r3_group(KS) * KS * 2048 + (size_t)R3_NW * R3_WBUF; }
+// ring slots: the stage being multiplied and the ones on their way.  (Four slots at C4's depth -- a stage there is ONE element tile --
+// were measured and change nothing: 0.385 / 0.383 ms, tools/r04_run_n.sh; what a stage waits for is not the image.)
+#ifndef R3_RING13
+#define R3_RING13 3
+#endif
+__host__ __device__ constexpr int r3_ring(int KS) { return KS == 13 ? R3_RING13 : 3; }
+__host__ __device__ inline size_t r3_lds_bytes(int d, int KS) { return pad1k((size_t)d * 4) + (size_t)r3_ring(KS) * r3_group(KS) * KS * 2048 + (size_t)R3_NW * R3_WBUF; }
 
 // ------------------------------------------------------------------------------------------------ pack
 // W_out image for v_mfma_f32_32x32x16_f16: fragment (mt, ks, piece) = 1 KiB = the A operand: lane l holds element 32 mt + (l & 31),
@@ -94,11 +100,11 @@ template <int KS, int CPF>
 __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
 {
     constexpr int G = r3_group(KS);                               // element tiles per stage: 4, 2 or 1
+    constexpr int RD = r3_ring(KS);                               // ring slots
     constexpr int STAGE = G * KS * 2048;
     constexpr int NPC = G * KS * 2;                               // 1-KiB pieces per stage
     constexpr int NPB = NPC / R3_NW, NPX = NPC % R3_NW;           // per wave: NPB, one more on waves < NPX
     constexpr int NSS = 4 * G;                                    // store instructions per wave and stage (4 per element tile)
-    constexpr int NS2 = 2 * NSS;                                  // ... in two consecutive stages
     constexpr bool PREF = CPF != 0;
     constexpr int LM = PREF ? (16 * KS) / CPF : 1;                // levels a prefetching instantiation can hold (c == CPF)
     constexpr int NL = PREF ? (32 * CPF + 63) / 64 : 1;           // plane floats per lane and level (a wave's 32 tokens x CPF, lane-contiguous)
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned bias_bytes = (unsigned)pad1k((size_t)p.d * 4);
     const unsigned off_ring = bias_bytes;
-    char *wbuf = smem + off_ring + 3 * STAGE + wave * R3_WBUF;
+    char *wbuf = smem + off_ring + RD * STAGE + wave * R3_WBUF;
     const int Tsh = r3_shift_of(*p.maxbits);
     const int Tc = Tsh > 100 ? 100 : Tsh < -100 ? -100 : Tsh;
     const float bsc = r3_pow2(Tc) * (float)(1 << R3_CV_SHIFT);      // accumulators live at scale 2^(T + shift) ...
@@ -164,10 +170,9 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
     };
     load_raw(blockIdx.x);
     __syncthreads();
-    issue(0, 0);
-    issue(1, 1);
+    static_for<0, RD - 1>([&](auto i_c) { issue(decltype(i_c)::value, decltype(i_c)::value); });
     int slot = 0;
-    int sdone = 0;                // stages done so far (saturating at 2): the first two of the kernel have fewer stores behind them
+    int sdone = 0;                // stages done so far (saturating at RD - 1): the first ones of the kernel have fewer stores behind them
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const long long tile0 = tile * R3_TILE;
         const long long tile_end = tile0 + R3_TILE < p.n_tokens ? tile0 + R3_TILE : p.n_tokens;
@@ -215,15 +220,34 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
                         }
                     });
                 } else {
-                    const int CVS = p.cvs;
-                    const int l_lo = k0 / p.c, l_hi = (k0 + VT - 1) / p.c;  // levels with a value in [k0, k0 + VT)
-                    for (int l = l_lo; l <= l_hi && l < p.levels; ++l) {
-                        const float *pl = p.cvf + ((size_t)l * p.tok_pad + trow0) * CVS;
-                        for (int idx = lane; idx < 32 * CVS; idx += 64) {
-                            const int tk = idx / CVS;
-                            const int comp = idx - tk * CVS;
-                            const int k = l * p.c + comp - k0;
-                            if (comp < p.c && k >= 0 && k < VT) put(pl[(tk < rows_ok ? tk : rows_ok - 1) * CVS + comp], tk, k);
+                    // any plane width: the planes of the levels with a value in this trip are rows of 64 floats (NR per level, one float per
+                    // lane and row); up to 32 rows are fetched as ONE batch, then cut into pieces -- one load, one wait, one value at a
+                    // time (the first form of this branch) paid a memory round trip per value: 128 of them per tile at C4, 0.1 ms of 0.33
+                    const int l_lo = k0 / p.c;
+                    int l_hi = (k0 + VT - 1) / p.c;
+                    l_hi = l_hi < p.levels ? l_hi : p.levels - 1;
+                    const int NR = (32 * p.cvs + 63) >> 6;
+                    const int nrow = (l_hi - l_lo + 1) * NR;
+                    const unsigned rcp = ((1u << 20) + (unsigned)p.cvs - 1u) / (unsigned)p.cvs;      // idx / cvs = idx rcp >> 20 (idx < 512, cvs <= 16)
+                    for (int r0 = 0; r0 < nrow; r0 += 32) {
+                        float rawt[32];
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                            const int rr = r0 + i, lq = rr / NR, it = rr - lq * NR;            // (uniform: scalar arithmetic)
+                            const unsigned idx = (unsigned)(it * 64 + lane), tk = (idx * rcp) >> 20, comp = idx - tk * (unsigned)p.cvs;
+                            // (no branch round the load: hipcc waits for ALL loads at a branch's end; a row the lane has nothing in reads the
+                            //  trip's first float instead)
+                            const bool ok = rr < nrow && idx < 32u * (unsigned)p.cvs;
+                            const float *pl = p.cvf + ((size_t)(l_lo + (rr < nrow ? lq : 0)) * p.tok_pad + trow0) * p.cvs;
+                            const float v = pl[ok ? ((int)tk < rows_ok ? tk : (unsigned)(rows_ok - 1)) * (unsigned)p.cvs + comp : 0u];
+                            rawt[i] = ok ? v : 0.0f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                            const int rr = r0 + i, lq = rr / NR, it = rr - lq * NR;
+                            const unsigned idx = (unsigned)(it * 64 + lane), tk = (idx * rcp) >> 20, comp = idx - tk * (unsigned)p.cvs;
+                            const int k = (l_lo + lq) * p.c + (int)comp - k0;
+                            if (rr < nrow && idx < 32u * (unsigned)p.cvs && (int)comp < p.c && k >= 0 && k < VT) put(rawt[i], (int)tk, k);
                         }
                     }
                 }
@@ -300,17 +324,18 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
             // next tile lie there too at a tile boundary; not counting them waits for a few operations more than needed, never fewer.)
             if (!fullw) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ragged wave: its store count is not static
-            } else if (wave < NPX) {
-                if (sdone >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + NS2) : "memory");
-                else if (sdone == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1 + NSS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + 1) : "memory");
             } else {
-                if (sdone >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NS2) : "memory");
-                else if (sdone == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB + NSS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB) : "memory");
+                // younger than this stage's pieces: those of the RD - 2 stages issued after it, and the stores of the min(sdone, RD - 1) stages between
+                static_for<0, RD>([&](auto n_c) {
+                    constexpr int n = decltype(n_c)::value;
+                    if (sdone == n) {
+                        if (wave < NPX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 2) * (NPB + 1) + n * NSS) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 2) * NPB + n * NSS) : "memory");
+                    }
+                });
             }
             __builtin_amdgcn_s_barrier();      // every wave's pieces of this stage landed; every wave has left the stage before
-            issue(s + 2, slot == 0 ? 2 : slot - 1);      // slot (s + 2) % 3 was read last in the stage before
+            issue(s + RD - 1, slot == 0 ? RD - 1 : slot - 1);      // slot (s + RD - 1) % RD was read last in the stage before
             const char *wb = smem + off_ring + slot * STAGE + lane * 16;
             if (active) {
 #pragma unroll
@@ -322,8 +347,8 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
                     tile_out(a0, (s * G + gi) * 32);
                 }
             }
-            slot = slot == 2 ? 0 : slot + 1;
-            sdone = sdone < 2 ? sdone + 1 : 2;
+            slot = slot == RD - 1 ? 0 : slot + 1;
+            sdone = sdone < RD - 1 ? sdone + 1 : RD - 1;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stages issued past the last tile must have landed before the workgroup's LDS is handed on

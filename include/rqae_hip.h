@@ -186,12 +186,16 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
  * The matrix-core arm of RQAE.forward ("gram arm", csrc/gram.hip).  Same inputs and outputs as
  * rqae_hip_encode (rqae/model.py:199-230), different arithmetic: lin_in of every level as ONE [tokens,d] x [d,L*c]
  * product, the level chain in c-space on precomputed c x c Gram blocks W_in[l] W_out[m], the
- * reconstruction as the decode sum (rqae/model.py:236-248) -- all three products on v_mfma_f32_16x16x32_bf16 with fp32
- * operands cut into three exact bf16 pieces.  Results carry fp32-level rounding but are not the bits of
- * rqae_hip_encode: parity is SURVEY 8(c) Tier 2 (codes identical wherever the top-1/top-2 cosine margin is
- * >= 1e-5; q_out within 1e-5 relative).  Exact duplicate codebook rows still resolve to the lowest index.
- *   rqae_hip_gram_supported      1 if the shape is served (d % 128 == 0, c <= 5, L <= 64, one codebook shared by all
- *                                levels and small enough to stay in LDS), else 0 -> use rqae_hip_encode
+ * reconstruction as the decode sum (rqae/model.py:236-248) -- products on the matrix cores with every fp32 operand cut into
+ * low-precision pieces: two fp16 pieces per value (hi = rn16(v 2^T), lo = rn16(v 2^T - hi), T an exact power of two found at pack
+ * time; three products per operand pair) on v_mfma_f32_32x32x16_f16 in the default kernels of round 4 (proj = 4, recon = 3, the
+ * sign chain, the products of calls deeper than 64 levels), three bf16 pieces (six products) on v_mfma_f32_16x16x32_bf16 in the
+ * kernels of rounds 2-3.  Results carry fp32-level rounding but are not the bits of rqae_hip_encode: parity is SURVEY 8(c) Tier 2
+ * (codes identical wherever the top-1/top-2 cosine margin is >= 1e-5; q_out within 1e-5 relative).  Exact duplicate codebook rows
+ * still resolve to the lowest index.  An input value beyond fp16's range (|x| > 65504 in bf16 / fp16 / fp32 hidden states) makes its
+ * token's projection non-finite: row 0 at every level and a NaN reconstruction, as a non-finite row does (rqae/model.py:182,188).
+ *   rqae_hip_gram_supported      1 if the shape is served (d % 128 == 0, c <= 13, L <= 1024; see DESIGN.md sections 9, 12, 13 for
+ *                                the codebook forms), else 0 -> use rqae_hip_encode
  *   rqae_hip_gram_packed_bytes   size of the arm's own parameter block (0 = unsupported)
  *   rqae_hip_gram_pack           builds it from the stacked fp32 tensors (same arguments as rqae_hip_pack)
  *   rqae_hip_gram_workspace_bytes scratch the caller lends to one rqae_hip_encode_gram call: the projections
@@ -203,8 +207,10 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
  *                                last pass, in milliseconds
  */
 int rqae_hip_gram_supported(int d, int c, int K, int L, int codebook_shared);
-/* one call with `levels` levels: the codes can always be had on a supported shape; the reconstruction (want_recon != 0) needs one of
- * the instantiated reconstruction kernels (32 levels at c = 4, 24 at c = 5, 16 at 6 <= c <= 13) */
+/* one call with `levels` levels.  Up to 64 levels the codes can always be had on a supported shape and the reconstruction
+ * (want_recon != 0) needs one of the instantiated reconstruction kernels (32 levels at c = 4, 24 at c = 5, 16 at 6 <= c <= 13).  Beyond 64 levels
+ * (the released model's 1024: DESIGN.md 13.4) the call runs whole blocks of 32 levels of a c = 4 shape with L % 64 == 0 and a shared
+ * FSQ lattice codebook, and must pass lean_levels = 5. */
 int rqae_hip_encode_gram_supported(int d, int c, int K, int L, int codebook_shared, int levels, int want_recon);
 size_t rqae_hip_gram_packed_bytes(int d, int c, int K, int L, int codebook_shared);
 int rqae_hip_gram_pack(void *packed, int d, int c, int K, int L, const float *w_in, const float *b_in,
@@ -229,8 +235,10 @@ size_t rqae_hip_gram_workspace_bytes(int d, int c, int K, int L, int64_t n_token
  * policy; they differ in speed.
  *   size        sizeof(rqae_hip_gram_options) (lets the struct grow)
  *   fused       1: one persistent kernel (projection + level chain + reconstruction per 256-token tile)        (0)
- *   proj        3: LDS-DMA projection kernel, 2: register-pipelined, 1: first form                               (3)
- *   recon       2: token-stationary reconstruction with 512-byte store rows, 1: weights-stationary               (2)
+ *   proj        4: fp16 two-piece projection, every output tile in one launch; 3: LDS-DMA projection kernel
+ *               of round 3, 2: register-pipelined, 1: first form                                                  (4)
+ *   recon       3: fp16 two-piece reconstruction (with it C4's level chain runs as matrix products, 13.5);
+ *               2: token-stationary reconstruction of round 3 with 512-byte store rows, 1: weights-stationary     (3)
  *   lean_levels the level chain.  4 = for a codebook that rqae_hip_gram_pack found to be an FSQ lattice ({linspace(-1, 1, n)}^c,
  *               rows of unit length or plain: rqae/model.py:63-72) the lattice form -- the rows that can win follow from the
  *               signs and the order of |projection| (6 of 1024 at n = 4, c = 5), each scored like the scan's rescoring scores

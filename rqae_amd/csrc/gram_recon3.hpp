@@ -16,10 +16,11 @@
 //   * the pieces of a wave's 32 tokens for ALL k-steps stay in registers (B operand: KS x 8 registers), built once per token tile
 //     from the level chain's fp32 planes through the wave's LDS buffer; any depth up to 16 k-steps (256 values) -- C2, C4, C5 and
 //     the released shape at depth <= 64 take the same kernel (the three earlier kernels split these shapes between them);
-//   * every store instruction writes ONE token row of 1 KiB (NT = 8 element tiles per block) or two rows of 512 bytes (NT = 4).
+//   * a finished element tile (32 tokens x 32 elements) goes through the wave's LDS buffer with every lane writing and leaves as 8
+//     token rows x 128 bytes per store instruction, non-temporal (see the kernel's comment for why not wider).
 // One workgroup = 8 waves x 32 tokens (one workgroup per CU, two waves per SIMD), persistent over 256-token tiles.  The W_out
-// image streams L2 -> LDS by LDS-DMA through a 3-slot ring, G element tiles (all k-steps, both pieces) per stage; counted vmcnt
-// waits and one raw barrier per stage, as in gram_fused_kernel.  Tier-2 parity like the rest of the arm.
+// image streams L2 -> LDS by LDS-DMA through a ring of r3_ring(KS) slots, G element tiles (all k-steps, both pieces) per stage; counted
+// vmcnt waits and one raw barrier per stage, as in gram_fused_kernel.  Tier-2 parity like the rest of the arm.
 
 constexpr int R3_NW = 8;                 // waves per workgroup
 constexpr int R3_TILE = R3_NW * 32;      // tokens per tile

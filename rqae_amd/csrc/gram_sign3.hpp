@@ -20,7 +20,9 @@
 // the 13 fall to one half, whatever the level's first column); the image of G is packed with the same deal.  The two lanes of a token
 // exchange one word per level (their halves of the sign pattern, v_permlane32_swap) and one float (their halves of sum q^2: a zero or
 // non-finite projection takes row 0, rqae/model.py:182,188).  The image (68 fragments pairs of 2 KiB: every (level, later tile))
-// sits in LDS, read through a register ring two pairs ahead of the matrix instructions.
+// sits in LDS (staged once per workgroup); each level's fragment pairs are read two pairs ahead of the matrix instructions that take them
+// (plain LDS loads put in order with sched_group_barrier: an asm read whose register hipcc spills between the read and its wait
+// reloads stale data -- the first version of this kernel did, from level 6 on).
 //
 // Same outputs as the lattice form: codes, and the straight-through values q + (cv - q) as fp32 planes [level][tok_pad][16] for
 // gram_recon3_kernel.  Arithmetic: the Gram updates are 2^-22-accurate products accumulated in fp32 in the matrix pipe's order, where the
@@ -65,7 +67,6 @@ struct Sign3Params {
 
 constexpr int S3_NW = 8;
 constexpr int S3_TILE = S3_NW * 32;
-constexpr int S3_PF = 1;         // fragment pairs read ahead
 
 // the other lane of the token (r, h) <-> (r, 1 - h)
 __device__ __forceinline__ unsigned s3_other(unsigned v, int h)

@@ -25,7 +25,7 @@ def short(k):
 def main():
     src = sys.argv[1]
     j = json.load(open(src))
-    ks = {k: v for k, v in j["kernels"].items() if any(t in k for t in ("gram_fused_kernel", "gram_levels", "gram_proj", "gram_recon", "deep_"))}
+    ks = {k: v for k, v in j["kernels"].items() if any(t in k for t in ("gram_fused_kernel", "gram_levels", "gram_proj", "gram_recon", "deep_", "sign_chain"))}
     configs = "--configs" in sys.argv      # the pass over bench.py's `configs` block: a per-kernel summary only (no C2 traffic file)
     rd = sum(v.get("hbm_read_bytes", 0.0) for v in ks.values())
     wr = sum(v.get("hbm_write_bytes", 0.0) for v in ks.values())

@@ -11,5 +11,5 @@ python bench.py --codes-only --no-cpu-baseline --no-extra-legs > $R/bench_codes_
 cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$R/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-legs --no-parity > $GRAFT_REPO_ROOT/$R/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$R/rocprof.err &&
 cd $GRAFT_REPO_ROOT &&
 python3 tools/pmc.py --pass-timeout 150 --out $R/pmc.json --kernels "gram_" --skip-launches 2 -- python3 bench.py --no-cpu-baseline --no-extra-legs --no-parity --no-configs --spinup-ms 0 --steps 4 --warmup 2 > $R/pmc.log 2>&1 &&
-python3 tools/pmc.py --pass-timeout 200 --out $R/pmc_configs.json --kernels "gram_|deep_" -- python3 bench.py --no-cpu-baseline --no-extra-legs --no-parity --spinup-ms 0 --steps 2 --warmup 1 > $R/pmc_configs.log 2>&1
+python3 tools/pmc.py --pass-timeout 200 --out $R/pmc_configs.json --kernels "gram_|deep_|sign_" -- python3 bench.py --no-cpu-baseline --no-extra-legs --no-parity --spinup-ms 0 --steps 2 --warmup 1 > $R/pmc_configs.log 2>&1
 tail -3 $R/pmc.log $R/pmc_configs.log; ls $R $R/stats

@@ -188,7 +188,8 @@ int rqae_hip_subfeature_sims(const float *codebook, const float *w_out, const fl
  * product, the level chain in c-space on precomputed c x c Gram blocks W_in[l] W_out[m], the
  * reconstruction as the decode sum (rqae/model.py:236-248) -- products on the matrix cores with every fp32 operand cut into
  * low-precision pieces: two fp16 pieces per value (hi = rn16(v 2^T), lo = rn16(v 2^T - hi), T an exact power of two found at pack
- * time; three products per operand pair) on v_mfma_f32_32x32x16_f16 in the default kernels of round 4 (proj = 4, recon = 3, the
+ * time; three products per operand pair -- hi hi, hi lo, lo hi; the lo lo product, below 2^-22 of the term, is not formed, and
+ * a 2-byte activation is a single piece: two products) on v_mfma_f32_32x32x16_f16 in the default kernels of round 4 (proj = 4, recon = 3, the
  * sign chain, the products of calls deeper than 64 levels), three bf16 pieces (six products) on v_mfma_f32_16x16x32_bf16 in the
  * kernels of rounds 2-3.  Results carry fp32-level rounding but are not the bits of rqae_hip_encode: parity is SURVEY 8(c) Tier 2
  * (codes identical wherever the top-1/top-2 cosine margin is >= 1e-5; q_out within 1e-5 relative).  Exact duplicate codebook rows

@@ -37,14 +37,14 @@ inline int r3_ks_template(int ks)
     return 0;
 }
 // element tiles per ring stage: stages of 16-32 KiB (three of them beside 36 KiB of wave buffers and the bias sums)
-__host__ __device__ constexpr int r3_group(int KS) { return KS <= 4 ? 4 : KS <= 8 ? 2 : 1; }
+__host__ __device__ constexpr int r3_group(int KS, int TS = 1) { return TS == 2 ? (KS <= 4 ? 2 : 1) : KS <= 4 ? 4 : KS <= 8 ? 2 : 1; }
 // ring slots: the stage being multiplied and the ones on their way.  (Four slots at C4's depth -- a stage there is ONE element tile --
 // were measured and change nothing: 0.385 / 0.383 ms, tools/r04_run_n.sh; what a stage waits for is not the image.)
 #ifndef R3_RING13
 #define R3_RING13 3
 #endif
 __host__ __device__ constexpr int r3_ring(int KS) { return KS == 13 ? R3_RING13 : 3; }
-__host__ __device__ inline size_t r3_lds_bytes(int d, int KS) { return pad1k((size_t)d * 4) + (size_t)r3_ring(KS) * r3_group(KS) * KS * 2048 + (size_t)R3_NW * R3_WBUF; }
+__host__ __device__ inline size_t r3_lds_bytes(int d, int KS, int TS = 1) { return pad1k((size_t)d * 4) + (size_t)r3_ring(KS) * r3_group(KS, TS) * KS * 2048 + (size_t)R3_NW * R3_WBUF; }
 
 // ------------------------------------------------------------------------------------------------ pack
 // W_out image for v_mfma_f32_32x32x16_f16: fragment (mt, ks, piece) = 1 KiB = the A operand: lane l holds element 32 mt + (l & 31),
@@ -97,15 +97,19 @@ struct Rec3Params {
 // writing (a ds_write_b128 occupies the LDS for its full 1-KiB slot however few lanes are active: the first form of this kernel,
 // with quarter-active writes of eight tiles at once, spent 0.33 of its 0.49 ms there), and leaves as 8 token rows x 128 bytes per
 // store instruction (5.82 TB/s on the full chip against 6.07 for 1-KiB rows, profiles/r02_store_patterns.txt).
-template <int KS, int CPF>
+// TS: sets of 32 tokens per wave (1 or 2).  With two, a weight fragment read from LDS feeds six matrix instructions instead of three and a
+// 512-token tile passes the image, its LDS-DMA and its barriers once: the stage's fixed work per token halves (the pieces of both sets
+// must fit the registers: KS <= 8).
+template <int KS, int CPF, int TS = 1>
 __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
 {
-    constexpr int G = r3_group(KS);                               // element tiles per stage: 4, 2 or 1
+    constexpr int G = r3_group(KS, TS);                           // element tiles per stage: 4, 2 or 1
+    constexpr int TILE = R3_TILE * TS;                            // tokens per tile
     constexpr int RD = r3_ring(KS);                               // ring slots
     constexpr int STAGE = G * KS * 2048;
     constexpr int NPC = G * KS * 2;                               // 1-KiB pieces per stage
     constexpr int NPB = NPC / R3_NW, NPX = NPC % R3_NW;           // per wave: NPB, one more on waves < NPX
-    constexpr int NSS = 4 * G;                                    // store instructions per wave and stage (4 per element tile)
+    constexpr int NSS = 4 * G * TS;                               // store instructions per wave and stage (4 per element tile and token set)
     constexpr bool PREF = CPF != 0;
     constexpr int LM = PREF ? (16 * KS) / CPF : 1;                // levels a prefetching instantiation can hold (c == CPF)
     constexpr int NL = PREF ? (32 * CPF + 63) / 64 : 1;           // plane floats per lane and level (a wave's 32 tokens x CPF, lane-contiguous)
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
     const float isc = 1.0f / bsc;                                    // ... an exact power of two either way
     const int nstg = p.d / (32 * G);                                // stages per tile (d % 128 == 0: whole stages, whole pairs)
     const int kval = p.c * p.levels;                                // values in use
-    const long long ntile = (p.n_tokens + R3_TILE - 1) / R3_TILE;
+    const long long ntile = (p.n_tokens + TILE - 1) / TILE;
     if ((long long)blockIdx.x >= ntile) return;
     // bias sums, scaled, once per workgroup
     for (int i = tid; i < (int)(bias_bytes >> 2); i += R3_NW * 64) reinterpret_cast<float *>(smem)[i] = i < p.d ? p.bias[i] * bsc : 0.0f;
@@ -140,20 +144,22 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
         }
     };
     // the wave's rows of a tile: first row, how many exist (rows past the batch re-read the last one; never stored)
-    auto rows_of = [&](long long tile, long long &trow0, int &rows_ok) {
-        const long long tile0 = tile * R3_TILE;
-        const long long tile_end = tile0 + R3_TILE < p.n_tokens ? tile0 + R3_TILE : p.n_tokens;
-        const long long tw0 = tile0 + (long long)wave * 32;
+    auto rows_of = [&](long long tile, int ts, long long &trow0, int &rows_ok) {
+        const long long tile0 = tile * TILE;
+        const long long tile_end = tile0 + TILE < p.n_tokens ? tile0 + TILE : p.n_tokens;
+        const long long tw0 = tile0 + (long long)(wave * TS + ts) * 32;
         const bool act = tw0 < tile_end;
         rows_ok = act ? (int)(tile_end - tw0 < 32 ? tile_end - tw0 : 32) : 1;
         trow0 = act ? tw0 : tile_end - 1;
     };
     // PREF: the raw values of a tile, lane-contiguous per level (idx = it 64 + lane over the wave's 32 x CPF floats)
-    float raw[LM * NL];
+    float raw[TS * LM * NL];
     auto load_raw = [&](long long tile) {
         if constexpr (PREF) {
+          static_for<0, TS>([&](auto ts_c) {
+            constexpr int ts = decltype(ts_c)::value;
             long long trow0; int rows_ok;
-            rows_of(tile, trow0, rows_ok);
+            rows_of(tile, ts, trow0, rows_ok);
             static_for<0, LM>([&](auto l_c) {
                 constexpr int l = decltype(l_c)::value;
                 if (l < p.levels) {
@@ -163,10 +169,11 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
                         const int idx = it * 64 + lane;
                         const int tk = idx / CPF, comp = idx - tk * CPF;
                         const int tsrc = tk < rows_ok ? tk : rows_ok - 1;
-                        raw[l * NL + it] = idx < 32 * CPF ? pl[tsrc * CPF + comp] : 0.0f;
+                        raw[(ts * LM + l) * NL + it] = idx < 32 * CPF ? pl[tsrc * CPF + comp] : 0.0f;
                     }
                 }
             });
+          });
         }
     };
     load_raw(blockIdx.x);
@@ -175,20 +182,21 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
     int slot = 0;
     int sdone = 0;                // stages done so far (saturating at RD - 1): the first ones of the kernel have fewer stores behind them
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const long long tile0 = tile * R3_TILE;
-        const long long tile_end = tile0 + R3_TILE < p.n_tokens ? tile0 + R3_TILE : p.n_tokens;
-        const long long tw0 = tile0 + (long long)wave * 32;
+        const long long tile0 = tile * TILE;
+        const long long tile_end = tile0 + TILE < p.n_tokens ? tile0 + TILE : p.n_tokens;
+        const long long tw0 = tile0 + (long long)wave * 32 * TS;       // the wave's first token (set ts: + 32 ts)
         const bool active = tw0 < tile_end;
-        const bool fullw = tw0 + 32 <= tile_end;
+        const bool fullw = tw0 + 32 * TS <= tile_end;
         // ---- this wave's token pieces (B operands), R3_BK k-steps per trip through the wave's buffer: rows of 32 BK hi + 32 BK lo bytes
-        u32x4 Ahi[KS], Alo[KS];
-        {
+        u32x4 Ahi[TS][KS], Alo[TS][KS];
+        static_for<0, TS>([&](auto ts_c) {
+            constexpr int ts = decltype(ts_c)::value;
             constexpr int VT = 16 * R3_BK;                          // values per trip
             constexpr int HB = 2 * VT;                              // bytes of a row's hi pieces; the lo pieces follow
             constexpr int RS = 2 * HB + 16;                         // row stride: 16 bytes x an odd number (conflict-free b128 reads)
             static_assert(32 * RS <= R3_WBUF, "a trip's rows fit the wave's buffer");
             long long trow0; int rows_ok;
-            rows_of(tile, trow0, rows_ok);
+            rows_of(tile, ts, trow0, rows_ok);
             static_for<0, (KS + R3_BK - 1) / R3_BK>([&](auto t_c) {
                 constexpr int TR = decltype(t_c)::value;
                 const int k0 = VT * TR;                             // first value of this trip
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
                                 const int idx = it * 64 + lane;
                                 const int tk = idx / CPF, comp = idx - tk * CPF;
                                 const int k = l * p.c + comp - k0;
-                                if (idx < 32 * CPF && comp < p.c && k >= 0 && k < VT) put(raw[l * NL + it], tk, k);
+                                if (idx < 32 * CPF && comp < p.c && k >= 0 && k < VT) put(raw[(ts * LM + l) * NL + it], tk, k);
                             }
                         }
                     });
@@ -256,20 +264,20 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
 #pragma unroll
                 for (int kl = 0; kl < R3_BK; ++kl)
                     if (R3_BK * TR + kl < KS) {
-                        Ahi[R3_BK * TR + kl] = *reinterpret_cast<const u32x4 *>(wbuf + r * RS + (16 * kl + 8 * h) * 2);
-                        Alo[R3_BK * TR + kl] = *reinterpret_cast<const u32x4 *>(wbuf + r * RS + HB + (16 * kl + 8 * h) * 2);
+                        Ahi[ts][R3_BK * TR + kl] = *reinterpret_cast<const u32x4 *>(wbuf + r * RS + (16 * kl + 8 * h) * 2);
+                        Alo[ts][R3_BK * TR + kl] = *reinterpret_cast<const u32x4 *>(wbuf + r * RS + HB + (16 * kl + 8 * h) * 2);
                     }
                 wave_sync_lds();
             });
-        }
+        });
         float *orow = p.out + (size_t)tw0 * p.d;
         // one element tile: 3 KS matrix instructions on one accumulator that starts at the scaled bias sum; back to scale 1 at the end
-        auto tile_mm = [&](const char *wb, int gi, int mt_abs) -> f32x16 {
-            f32x16 a;
+        auto tile_mm = [&](const char *wb, int gi, int mt_abs, f32x16 (&a)[TS]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {       // lane (token r, half h) holds elements 32 mt + 8 i + 4 h + 0..3
                 const f32x4 b = *reinterpret_cast<const f32x4 *>(smem + ((size_t)mt_abs * 32 + 8 * i + 4 * h) * 4);
-                a[4 * i] = b[0]; a[4 * i + 1] = b[1]; a[4 * i + 2] = b[2]; a[4 * i + 3] = b[3];
+#pragma unroll
+                for (int ts = 0; ts < TS; ++ts) { a[ts][4 * i] = b[0]; a[ts][4 * i + 1] = b[1]; a[ts][4 * i + 2] = b[2]; a[ts][4 * i + 3] = b[3]; }
             }
             u32x4 fh[KS], fl[KS];
 #pragma unroll
@@ -279,15 +287,19 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (R3_ABL & 1) {
-                    a[0] += f32_bits(fh[ks][0] ^ Ahi[ks][0] ^ fl[ks][1] ^ Alo[ks][1]);
-                } else {
-                    a = mfma32(fh[ks], Ahi[ks], a);
-                    a = mfma32(fh[ks], Alo[ks], a);
-                    a = mfma32(fl[ks], Ahi[ks], a);
+#pragma unroll
+                for (int ts = 0; ts < TS; ++ts) {
+                    if (R3_ABL & 1) {
+                        a[ts][0] += f32_bits(fh[ks][0] ^ Ahi[ts][ks][0] ^ fl[ks][1] ^ Alo[ts][ks][1]);
+                    } else {
+                        a[ts] = mfma32(fh[ks], Ahi[ts][ks], a[ts]);
+                        a[ts] = mfma32(fh[ks], Alo[ts][ks], a[ts]);
+                        a[ts] = mfma32(fl[ks], Ahi[ts][ks], a[ts]);
+                    }
                 }
             }
-            return a * isc;
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) a[ts] = a[ts] * isc;
         };
         // "all reads, then all MFMAs" of one element tile put in order: the bias reads and two k-steps' fragments ahead, then a k-step's
         // fragments behind each k-step's three matrix instructions
@@ -297,15 +309,17 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
                 __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * PFK, 0);
 #pragma unroll
                 for (int ks = 0; ks < KS - PFK; ++ks) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * TS, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * PFK, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * TS * PFK, 0);
             }
         };
         // a finished element tile (elements el0 .. el0 + 31 of the wave's 32 tokens): every lane writes its token's 16 values, then
         // 4 x (8 rows x 128 bytes) come back and leave with non-temporal stores
-        auto tile_out = [&](const f32x16 &a0, int el0) {
+        auto tile_out = [&](const f32x16 &a0, int el0, int ts) {
+            float *orow_s = orow + (size_t)ts * 32 * p.d;
+            const long long tws = tw0 + 32 * ts;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 *reinterpret_cast<f32x4 *>(wbuf + r * TRS + (8 * i + 4 * h) * 4) = f32x4{a0[4 * i], a0[4 * i + 1], a0[4 * i + 2], a0[4 * i + 3]};
@@ -314,8 +328,8 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
             for (int i = 0; i < 4; ++i) {
                 const int row = 8 * i + (lane >> 3);
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(wbuf + row * TRS + (lane & 7) * 16);
-                if ((R3_ABL & 2) ? p.n_tokens < 0 : (fullw || tw0 + row < tile_end))
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(orow + (size_t)row * p.d + el0 + (lane & 7) * 4));
+                if ((R3_ABL & 2) ? p.n_tokens < 0 : (fullw || tws + row < tile_end))
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(orow_s + (size_t)row * p.d + el0 + (lane & 7) * 4));
             }
             wave_sync_lds();
         };
@@ -341,11 +355,13 @@ __global__ __launch_bounds__(R3_NW * 64) void gram_recon3_kernel(Rec3Params p)
             if (active) {
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi) {
-                    const f32x16 a0 = tile_mm(wb, gi, s * G + gi);
+                    f32x16 a0[TS];
+                    tile_mm(wb, gi, s * G + gi, a0);
                     tile_order();
                     // (the next tile's values before this tile's last stores: see CPF)
                     if (PREF && gi == G - 1 && s == nstg - 1 && tile + gridDim.x < ntile) load_raw(tile + gridDim.x);
-                    tile_out(a0, (s * G + gi) * 32);
+#pragma unroll
+                    for (int ts = 0; ts < TS; ++ts) tile_out(a0[ts], (s * G + gi) * 32, ts);
                 }
             }
             slot = slot == RD - 1 ? 0 : slot + 1;

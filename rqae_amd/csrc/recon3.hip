@@ -64,22 +64,37 @@ int launch(const Args &a, int ncu, hipStream_t s)
     Rec3Params pr;
     pr.wimg = static_cast<const uint16_t *>(a.img); pr.maxbits = a.maxbits; pr.bias = a.bias; pr.cvf = a.planes; pr.out = a.out;
     pr.n_tokens = a.n_tokens; pr.tok_pad = a.tok_pad; pr.d = a.d; pr.c = a.c; pr.levels = a.levels; pr.KS3 = (a.L * a.c + 15) / 16; pr.cvs = a.cvs;
-    long long nb = (a.n_tokens + R3_TILE - 1) / R3_TILE;
+    // planes of exactly c floats (the lean level chains, c == CP) at a depth the registers hold one tile ahead: the prefetching forms
+    bool pf4 = a.cvs == 4 && a.c == 4, pf5 = a.cvs == 5 && a.c == 5;
+    // two token sets per wave (512-token tiles): measured at 262 144 tokens (tools/r04_run_o.sh) -- C5's 8 k-steps 0.670 -> 0.621 ms, the
+    // store-bound depths no better (C2 0.479 / 0.489, P@16 0.485 / 0.502): taken at 8 k-steps when every CU still gets two tiles
+    int ts = kt == 8 && a.n_tokens >= 2LL * 2 * R3_TILE * ncu ? 2 : 1;
+#ifdef R3_TOOLS   /* tools builds: R3_FORCE=nopref (values loaded at the tile's start), ts1 / ts2 */
+    if (const char *e = getenv("R3_FORCE")) {
+        if (strstr(e, "nopref")) pf4 = pf5 = false;
+        if (strstr(e, "ts1")) ts = 1;
+        if (strstr(e, "ts2") && kt <= 8) ts = 2;
+    }
+#endif
+    const long long tile = (long long)R3_TILE * ts;
+    long long nb = (a.n_tokens + tile - 1) / tile;
     if (nb > ncu) nb = ncu;
-    const size_t lds = r3_lds_bytes(a.d, kt);
+    const size_t lds = r3_lds_bytes(a.d, kt, ts);
     auto go = [&](auto kern) -> int {
         R3_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(R3_NW * 64), lds, s, pr);
         R3_TRY(hipGetLastError());
         return 0;
     };
-    // planes of exactly c floats (the lean level chains, c == CP) at a depth the registers hold one tile ahead: the prefetching forms
-    bool pf4 = a.cvs == 4 && a.c == 4, pf5 = a.cvs == 5 && a.c == 5;
-#ifdef R3_TOOLS   /* tools builds: R3_FORCE=nopref (values loaded at the tile's start) */
-    if (const char *e = getenv("R3_FORCE")) {
-        if (strstr(e, "nopref")) pf4 = pf5 = false;
-    }
+    if (ts == 2)
+        switch (kt) {
+#ifdef R3_TOOLS
+        case 2: return pf4 ? go(gram_recon3_kernel<2, 4, 2>) : go(gram_recon3_kernel<2, 0, 2>);
+        case 3: return pf5 ? go(gram_recon3_kernel<3, 5, 2>) : pf4 ? go(gram_recon3_kernel<3, 4, 2>) : go(gram_recon3_kernel<3, 0, 2>);
+        case 4: return pf4 ? go(gram_recon3_kernel<4, 4, 2>) : go(gram_recon3_kernel<4, 0, 2>);
 #endif
+        case 8: return go(gram_recon3_kernel<8, 0, 2>);
+        }
     switch (kt) {
     case 2: return pf4 ? go(gram_recon3_kernel<2, 4>) : go(gram_recon3_kernel<2, 0>);
     case 3: return pf5 ? go(gram_recon3_kernel<3, 5>) : pf4 ? go(gram_recon3_kernel<3, 4>) : go(gram_recon3_kernel<3, 0>);

@@ -512,6 +512,27 @@ def test_sign_chain_and_its_fallback():
     check_tier2(xs, w2, None, idx2)
 
 
+def test_recon3_two_token_sets_per_wave():
+    """csrc/gram_recon3.hpp, TS = 2: at 8 k-steps (C5's shape) batches that give every CU two 512-token tiles take the form in which a
+    wave carries two sets of 32 tokens.  A ragged batch just above that size: its last tile holds 300 tokens (a full set, a partial set,
+    waves without tokens); the tail and a slice of the middle must come out bit for bit as the same tokens do in a small batch (one set
+    per wave) -- the matrix instructions of a token run in the same order in both forms."""
+    cfg = dict(synth.CONFIGS["C5"])
+    w = synth.weights(77, cfg["dim"], cfg["codebook_dim"], cfg["num_quantizers"], cfg["codebook_size"])
+    m = make_model(cfg, w, "gram")
+    n = 262144 + 300
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    z = torch.randn(n, cfg["dim"], device=DEV, generator=g)
+    xb = (z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16)
+    with torch.inference_mode():
+        q, idx = m(xb.view(1, n, -1))
+        for a, b in ((n - 812, n), (131072 - 100, 131072 + 156)):
+            q2, idx2 = m(xb[a:b].view(1, b - a, -1))
+            assert torch.equal(idx[0, a:b], idx2[0]) and torch.equal(q[0, a:b], q2[0])
+    sel = np.concatenate([np.arange(0, 2048), np.arange(n - 600, n)])
+    check_tier2(xb[sel].float().cpu().numpy(), w, q[0][sel].cpu().numpy(), idx[0][sel].cpu().numpy())
+
+
 def test_gram_decode_matches_the_exact_decode():
     """RQAE.decode on the matrix-core arm (rqae_hip_decode_gram: the reconstruction kernel fed by the codes) against the exact
     arm's decode, which is the oracle's and the reference capture's bits (test_hip_parity.py::test_decode): within 1e-6 of the

@@ -64,14 +64,15 @@ int convert(const float *planes, long long tok_pad, int nlev, int l0, void *piec
 
 static int launch(int mode, const Gemm &g, int ncu, hipStream_t s)
 {
-    if (g.ntiles % D3_NTB || g.nks < 1) return d3fail("deep gemm: %d output tiles, %d k-steps", g.ntiles, g.nks);
+    if (g.ntiles % 4 || g.nks < 1) return d3fail("deep gemm: %d output tiles, %d k-steps", g.ntiles, g.nks);
+    const int ntb = g.ntiles % 8 == 0 ? 8 : 4;      // eight tiles per pass wherever the columns allow (gram_deep3.hpp: operand traffic per matrix instruction)
     Deep3Params p;
     p.apieces = static_cast<const uint16_t *>(g.apieces); p.wimg = static_cast<const uint16_t *>(g.wimg); p.maxbits = g.maxbits;
     p.P = g.P; p.bias = g.bias; p.out = g.out; p.n_tokens = g.n_tokens; p.tok_pad = g.tok_pad; p.KSA = g.KSA; p.KSW = g.KSW; p.ks0 = g.ks0; p.nks = g.nks;
-    p.nt0 = g.nt0; p.npass = g.ntiles / D3_NTB; p.d = g.d;
+    p.nt0 = g.nt0; p.npass = g.ntiles / ntb; p.d = g.d;
     const long long items = ((g.n_tokens + D3_TILE - 1) / D3_TILE) * p.npass;
     long long nb = items < ncu ? items : ncu;
-    const size_t lds = d3_lds_bytes(mode, g.d);
+    const size_t lds = d3_lds_bytes(mode, g.d, ntb);
     if (lds > 160 * 1024) return d3fail("deep gemm: d=%d does not fit LDS", g.d);
     auto go = [&](auto kern) -> int {
         D3_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -79,7 +80,8 @@ static int launch(int mode, const Gemm &g, int ncu, hipStream_t s)
         D3_TRY(hipGetLastError());
         return 0;
     };
-    return mode == 0 ? go(deep_gemm_kernel<0>) : go(deep_gemm_kernel<1>);
+    if (ntb == 8) return mode == 0 ? go(deep_gemm_kernel<0, 8>) : go(deep_gemm_kernel<1, 8>);
+    return mode == 0 ? go(deep_gemm_kernel<0, 4>) : go(deep_gemm_kernel<1, 4>);
 }
 
 int corrections(const Gemm &g, int ncu, hipStream_t s) { return launch(0, g, ncu, s); }

@@ -20,12 +20,14 @@
 
 constexpr int D3_NW = 8;
 constexpr int D3_TILE = D3_NW * 32;
-constexpr int D3_NTB = 4;                // output tiles (of 32) per pass
+constexpr int D3_NTB = 4;                // output tiles (of 32) per pass: 4 (a block's 128 columns) or 8 (template argument NTB)
 constexpr int D3_KC = 4;                 // k-steps per chunk
-constexpr int D3_STAGE = D3_NTB * D3_KC * 2048;
+__host__ __device__ constexpr int d3_stage(int ntb) { return ntb * D3_KC * 2048; }
 constexpr int D3_WBUF = 4608;            // transposition bytes per wave (MODE 1)
 
-__host__ __device__ inline size_t d3_lds_bytes(int mode, int d) { return 2 * (size_t)D3_STAGE + (mode == 1 ? pad1k((size_t)d * 4) + (size_t)D3_NW * D3_WBUF : 0); }
+// (MODE 1's transposition buffers lie over the stages: the K loop is over when they are used)
+__host__ __device__ inline size_t d3_lds_bytes(int mode, int d, int ntb) { return 2 * (size_t)d3_stage(ntb) + (mode == 1 ? pad1k((size_t)d * 4) : 0); }
+static_assert(D3_NW * D3_WBUF <= 2 * d3_stage(4), "the waves' transposition buffers fit the two stages");
 
 // ------------------------------------------------------------------------------------------------ planes -> pieces
 // planes [nlev][tok_pad][4] fp32 (levels l0 .. l0 + nlev - 1 of the block, c = 4) -> fragments of k-steps ks0 .. ks0 + nlev / 4 - 1:
@@ -98,16 +100,20 @@ struct Deep3Params {
     int d;                       // MODE 1: row length of out
 };
 
-template <int MODE>
+// NTB: output tiles per pass.  The products are bound by their operands' way from L2 / the Infinity Cache (per chunk and wave 8 KiB of token
+// fragments + the wave's share of the weights' stage against NTB x 12 matrix instructions: 256 bytes per instruction at NTB = 4, 170 at
+// 8), so the wide products -- the reconstruction, the right-looking corrections -- take 8 tiles; a block's own 128 columns are 4.
+template <int MODE, int NTB>
 __global__ __launch_bounds__(D3_NW * 64) void deep_gemm_kernel(Deep3Params p)
 {
+    constexpr int D3_NTB = NTB, D3_STAGE = d3_stage(NTB);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned off_bias = 2u * D3_STAGE;
     const unsigned bias_bytes = MODE == 1 ? (unsigned)pad1k((size_t)p.d * 4) : 0u;
-    char *wbuf = smem + off_bias + bias_bytes + wave * D3_WBUF;
+    char *wbuf = smem + wave * D3_WBUF;          // over the stages, after the K loop (a barrier in between)
     const int Tsh = r3_shift_of(*p.maxbits);
     const int Tc = Tsh > 100 ? 100 : Tsh < -100 ? -100 : Tsh;
     const float bsc = r3_pow2(Tc) * (float)(1 << R3_CV_SHIFT);
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(D3_NW * 64) void deep_gemm_kernel(Deep3Params p)
                 if (active) mm(1, A1);
             }
         }
+        if constexpr (MODE == 1) __syncthreads();      // every wave has left the last stage: the stages now hold the waves' transposition buffers
         if (!active) continue;
         if constexpr (MODE == 0) {
             // lane (token r, half h) holds columns 32 (nt_first + o) + 8 i + 4 h + 0..3: group u = 2 nt + (i >> 1) of P[group][tok][16]

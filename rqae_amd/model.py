@@ -52,7 +52,8 @@ class RQAE(nn.Module):
     """Residual-quantisation autoencoder; see module docstring for the mapping."""
 
     GRAM_MIN_TOKENS = 16384   # arm="auto": below this the exact arm's single launch wins
-    GRAM_MIN_TOKENS_DEEP = 32768   # ... for calls of more than 64 levels (the blocked path: ~100 launches per pass of 131072 tokens)
+    GRAM_MIN_TOKENS_DEEP = 8192    # ... for calls of more than 64 levels (the blocked path: ~100 launches, 5.6 ms of them at any batch; measured at depth
+                                   # 1024: 4096 tokens exact 4.8 / gram 6.2 ms, 8192: 8.9 / 6.9, 16384: 17.9 / 8.0 -- DESIGN.md 13.4)
 
     PRETRAINED = {
         "google/gemma-2-2b": "harish-kamath/rqae/gemma-2-2b",

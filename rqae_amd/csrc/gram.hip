@@ -111,6 +111,17 @@ __host__ __device__ inline int nks_recon(const Geom &g, int levels)
     return full * (g.GS / 32) + (6 * g.CP * rem + 31) / 32;
 }
 
+// n with n^c == K (2 <= n <= 16), else 0: the lattice rqae_hip_gram_pack looks for (the device-side check confirms it or clears the header's word)
+inline int lattice_points(int K, int c)
+{
+    for (int n = 2; n <= 16; ++n) {
+        long long pw = 1;
+        for (int j = 0; j < c && pw <= K; ++j) pw *= n;
+        if (pw == K) return n;
+    }
+    return 0;
+}
+
 // a block that can run more than GRAM_DEEP_L levels (gram_deep3.hpp): c = 4, whole blocks of 32 levels and whole column blocks of the
 // projection (L % 64 == 0), one shared codebook whose fp32 rows fit the lattice form's LDS
 inline bool deep_block_ok(const Geom &g) { return g.L > GRAM_DEEP_L && g.c == 4 && g.L % 64 == 0 && g.shared_cb && (size_t)g.K * g.c * 4 <= 150 * 1024 && g.d % 128 == 0; }
@@ -1994,6 +2005,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
 #define LATK(CPV, MV, IV) (ceq ? go(gram_levels_wide_kernel<CPV, 4, MV, IV, true, true>) : go(gram_levels_wide_kernel<CPV, 4, MV, IV, true, false>))
             if (wide) rc = ceq ? go(gram_levels_wide_kernel<13, 8, true, false, true, true>) : go(gram_levels_wide_kernel<13, 8, true, false, true, false>);
             else if (lev2) rc = g.CP == 4 ? LATK(4, false, false) : LATK(5, false, false);
+            else if (lat_planes && multi && g.CP == 4 && ceq && lattice_points(K, c) == 8)
+                rc = go(gram_levels_wide_kernel<4, 4, true, false, true, true, 8>);      // C5's lattice: approximate scores choose (lattice_fast)
             else if (lat_planes) rc = multi ? (g.CP == 4 ? LATK(4, true, false) : LATK(5, true, false)) : (g.CP == 4 ? LATK(4, false, false) : LATK(5, false, false));
             else if (multi) rc = g.CP == 4 ? LATK(4, true, true) : LATK(5, true, true);
             else rc = g.CP == 4 ? LATK(4, false, true) : LATK(5, false, true);

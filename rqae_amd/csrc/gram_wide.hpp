@@ -77,8 +77,80 @@ template <> struct RowPtr<lds_cf32 *> {
     static __device__ __forceinline__ f32x4 quad(lds_cf32 *p, size_t i) { return *(lds_cf32x4 *)(p + i); }
 };
 
-template <int CP, typename PT>
-__device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, PT cbf)
+// ---- the fast form of the argmax for c = 4 lattices with three or four magnitudes (n = 5: the released shape; n = 8: C5), rows of unit
+// length.  The cosine of q with the candidate of thresholds (t_1 >= ... >= t_nth) is, in integer magnitudes M_k = M_0 + 2 k,
+//     ( M_0 S[c] + 2 sum_k S[t_k] ) / sqrt( c M_0^2 + sum_k t_k (M_k^2 - M_{k-1}^2) ),      S[t] = the t largest |q_j| summed,
+// -- two adds, one fma and one multiplication by a compile-time constant per candidate, no row fetched -- where the exact scoring
+// (the reference's q / ||q|| against the stored row, an fma chain in coordinate order) costs a gather and a dozen instructions.  The
+// approximate scores pick the candidate; the runner-up's distance says whether they may: within LAT_EPS (relative) of the best the
+// reference's fp32 rounding could decide otherwise, and the whole wave takes the exact enumeration below.  Candidates that are
+// multiples of one another (n odd: t coordinates at ONE magnitude, the rest zero; n even: every coordinate at the same magnitude) are
+// one direction: one of them is enumerated, and when it wins its members are scored exactly as stored, as the exact form does (the
+// stored rows of such a family are equal or an ulp apart: the reference's own rounding and its lowest-index rule decide there).
+constexpr float LAT_EPS = 8e-6f;
+template <int CP, int N, typename SC>
+__device__ __forceinline__ bool lattice_fast(const float (&a)[CP], int row0, const int (&PW)[CP + 1], SC &&exact_score, int &brow_out)
+{
+    constexpr bool EVEN = N % 2 == 0;
+    constexpr int NTH = (N + 1) / 2 - 1, M0 = EVEN ? 1 : 0;
+    static_assert(CP == 4 && (NTH == 2 || NTH == 3), "instantiated for c = 4, n = 5 / 8");
+    float S[CP + 1];
+    S[0] = 0.0f;
+#pragma unroll
+    for (int t = 1; t <= CP; ++t) S[t] = S[t - 1] + a[t - 1];
+    const float base = (float)M0 * S[CP];
+    float best = -INFINITY, second = -INFINITY;
+    int brow = row0, bfam = -1;                        // bfam: the winner is the family of t coordinates at one magnitude (n even: t = CP)
+    static_for<0, CP + 1>([&](auto t1_c) {
+        constexpr int t1 = decltype(t1_c)::value;
+        static_for<0, t1 + 1>([&](auto t2_c) {
+            constexpr int t2 = decltype(t2_c)::value;
+            static_for<0, (NTH == 3 ? t2 + 1 : 1)>([&](auto t3_c) {
+                constexpr int t3 = NTH == 3 ? decltype(t3_c)::value : 0;
+                // integer norm^2; family membership
+                constexpr int D1 = (M0 + 2) * (M0 + 2) - M0 * M0, D2 = (M0 + 4) * (M0 + 4) - (M0 + 2) * (M0 + 2), D3 = (M0 + 6) * (M0 + 6) - (M0 + 4) * (M0 + 4);
+                constexpr int N2 = CP * M0 * M0 + t1 * D1 + t2 * D2 + t3 * D3;
+                constexpr bool zero = N2 == 0;                                                    // n odd: the zero row (cosine 0: never the argmax of a non-zero q)
+                constexpr bool one_mag = EVEN ? ((t1 == 0 || t1 == CP) && (t2 == 0 || t2 == CP) && (t3 == 0 || t3 == CP))
+                                              : (t1 > 0 && (t2 == 0 || t2 == t1) && (t3 == 0 || t3 == t2) && !(t2 == 0 && t3 != 0));
+                constexpr bool rep = EVEN ? (t1 == 0) : (t2 == 0 && t3 == 0);                      // the member that is enumerated
+                if constexpr (!zero && (!one_mag || rep)) {
+                    const float inv = 1.0f / __builtin_sqrtf((float)N2);      // (folded at compile time)
+                    const float sc = __builtin_fmaf(2.0f, S[t1] + S[t2] + S[t3], base) * inv;
+                    const int row_s = row0 + PW[t1] + PW[t2] + PW[t3];
+                    const bool up = sc > best;
+                    second = up ? best : __builtin_fmaxf(second, sc);
+                    best = up ? sc : best;
+                    brow = up ? row_s : brow;
+                    bfam = up ? (one_mag ? (EVEN ? CP : t1) : -1) : bfam;
+                }
+            });
+        });
+    });
+    // a family won somewhere in the wave: its members (k magnitudes up: row0 + k PW[t]) scored as stored, first maximum = lowest row
+    if (__builtin_amdgcn_ballot_w64(bfam >= 0) != 0) {
+        int pwf = 0;
+#pragma unroll
+        for (int t = 1; t <= CP; ++t) pwf = bfam == t ? PW[t] : pwf;
+        float fs = -INFINITY;
+        int frow = row0;
+#pragma unroll
+        for (int k = (EVEN ? 0 : 1); k <= NTH; ++k) {
+            const int rk = row0 + k * pwf;
+            const float sk = exact_score(rk);
+            const bool up = (sk > fs) | ((sk == fs) & (rk < frow));
+            fs = up ? sk : fs;
+            frow = up ? rk : frow;
+        }
+        brow = bfam >= 0 ? frow : brow;
+    }
+    brow_out = brow;
+    return (best - second) > LAT_EPS * best;           // (false for a NaN or non-positive best: the exact form decides)
+}
+
+// FN: the lattice (5 or 8 points per coordinate) this instantiation may take lattice_fast for; 0: the exact enumeration only
+template <int CP, int FN = 0, typename PT>
+__device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, PT cbf, bool fast = false)
 {
     const int nth = (n + 1) / 2 - 1;                    // thresholds: magnitudes above the lowest one
     const int base_pos = n / 2, base_neg = (n & 1) ? n / 2 : n / 2 - 1;
@@ -107,8 +179,8 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
     // may land either way round: the two rows then score the same in real arithmetic (a tie the reference decides by rounding)
     int PW[CP + 1];
     PW[0] = 0;
+    float a[CP];
     if (nth > 0) {
-        float a[CP];
 #pragma unroll
         for (int jj = 0; jj < CP; ++jj) a[jj] = jj < c ? __builtin_fabsf(q[jj]) : -1.0f;
         auto cx = [&](auto i_c, auto j_c) __attribute__((always_inline)) {
@@ -138,7 +210,7 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
         for (int r = 0; r < CP; ++r) PW[r + 1] = PW[r] + w[r];
     } else {
 #pragma unroll
-        for (int r = 0; r < CP; ++r) PW[r + 1] = 0;
+        for (int r = 0; r < CP; ++r) { PW[r + 1] = 0; a[r] = 0.0f; }
     }
     int brow = 0;
     float bsc = -INFINITY;
@@ -181,6 +253,21 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
         });
         return brow;
     }
+    // three and more magnitudes, c = 4, rows of unit length: the approximate scores choose, unless some lane's runner-up is too close
+    if constexpr (CP == 4 && (FN == 5 || FN == 8)) {
+        if (fast && c == CP && n == FN) {
+            auto exact_score = [&](int row) __attribute__((always_inline)) -> float {
+                const f32x4 v = RowPtr<PT>::quad(cbf, (size_t)row * CP);
+                float sc = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc = __builtin_fmaf(xn[e], v[e], sc);
+                return sc;
+            };
+            int fr = row0;
+            const bool clear = lattice_fast<CP, FN>(a, row0, PW, exact_score, fr);
+            if (__builtin_amdgcn_ballot_w64(!clear) == 0) return fr;
+        }
+    }
     // three and more magnitudes (n >= 5: the pretrained shape, C5): the odometer walks the first nth - 1 thresholds, the last one
     // (0 .. its predecessor) is unrolled with PW indexed at compile time -- 12 vector instructions per candidate instead of 30
     const int no = nth - 1;                             // thresholds in the odometer
@@ -221,7 +308,8 @@ __device__ __forceinline__ int lattice_best(const float (&q)[CP], int c, int n, 
 // LAT: the lattice form -- no image, no scan, no loader waves, no LDS: lattice_best above picks the row; everything after it (the
 // straight-through values in the format the reconstruction reads, Gram updates, later groups' corrections, codes) is the same code.
 // CEQ: c == CP as a compile-time fact (no padded coordinate: the selects that mask one disappear).
-template <int CP, int NW, bool MULTI = true, bool IMG = (MULTI && CP <= 5), bool LAT = false, bool CEQ = false>
+// FN: see lattice_best (the host names the lattice it found from K and c; measured: n = 8 gains a third of the chain, n = 5 loses a tenth)
+template <int CP, int NW, bool MULTI = true, bool IMG = (MULTI && CP <= 5), bool LAT = false, bool CEQ = false, int FN = 0>
 __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 3 : 2)) void gram_levels_wide_kernel(LevParams p)
 {
     // the lattice form runs when the block's header says the codebook is a lattice; the scan forms launched behind it then return
@@ -270,6 +358,13 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
         __syncthreads();
     }
     lds_cf32 *lgram = ltab + ((p.K * p.c + 3) & ~3);
+    // rows of unit length ("round_fsq": the last row, every coordinate +1, is 1 / sqrt(c) each) let the lattice form choose by approximate
+    // scores (lattice_fast); plain rows ("fsq": 1.0) keep the exact enumeration.  LAT_EXACT: tools builds, the exact form everywhere
+#ifdef LAT_EXACT
+    const bool lat_fast = false;
+#else
+    const bool lat_fast = LAT && FN != 0 && __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cbf0[(size_t)(p.K - 1) * p.c]))) < 0.999f;
+#endif
     // lattice form, wide codebooks (C4): every Gram block a chain can need -- level l onto a later level l2, the upper triangle of
     // [L][L], 120 blocks of 172 floats = 82 KB at depth 16 -- staged in LDS once per workgroup.  Read from L2 by every wave for
     // itself (43 dwordx4 loads of one address per block, ~100 blocks per wave and level group) they bound the kernel on the
@@ -435,8 +530,8 @@ __global__ __launch_bounds__((LAT ? NW : NW + W_NWL) * 64, LAT ? 2 : (NW == 8 ? 
                     const bool okq = (n2 > 0.0f) && (n2 < INFINITY);
                     int brow;
                     if constexpr (LAT) {
-                        if constexpr (TAB) brow = lattice_best<CP>(q, c, nlat, ltab);
-                        else brow = lattice_best<CP>(q, c, nlat, cbf);
+                        if constexpr (TAB) brow = lattice_best<CP, FN>(q, c, nlat, ltab, lat_fast);
+                        else brow = lattice_best<CP, FN>(q, c, nlat, cbf, lat_fast);
                     } else {
                     brow = [&]() __attribute__((always_inline)) -> int {
                     // ---- B operand rows of the wave's 64 tokens: 96 slots = 3 k-steps x 64 bytes per token, one k-step per trip

@@ -1777,9 +1777,15 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
                 long long nb = (pl.ntiles + 3) / 4;
                 if (nb > 8LL * ncu) nb = 8LL * ncu;
                 const size_t lds = (((size_t)K * c * 4 + 15) & ~(size_t)15) + (size_t)(BL / g.GL) * g.GL * g.GL * g.GB * 4;
-                if (lds > 64 * 1024) G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_levels_wide_kernel<4, 4, true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((gram_levels_wide_kernel<4, 4, true, false, true, true>), dim3((unsigned)nb), dim3(256), lds, s, pl);
-                G_TRY(hipGetLastError());
+                // (the chain of a five-point lattice -- the released shape -- chooses by approximate scores: lattice_fast, gram_wide.hpp)
+                auto chain = [&](auto kern) -> int {
+                    if (lds > 64 * 1024) G_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, s, pl);
+                    G_TRY(hipGetLastError());
+                    return 0;
+                };
+                if (int rc = lattice_points(K, c) == 5 ? chain(gram_levels_wide_kernel<4, 4, true, false, true, true, 5>)
+                                                       : chain(gram_levels_wide_kernel<4, 4, true, false, true, true>)) return rc;
                 if (q_out || b + 1 < nblocks)
                     if (int rc = rqae_d3::convert(planes, dtp, BL, b * BL, pieces, L, s)) return rc;
                 if ((b + 1) % SBK == 0 && b + 1 < nblocks) {
@@ -2007,6 +2013,8 @@ int encode_gram_impl(const void *packed, int d, int c, int K, int L, int codeboo
             else if (lev2) rc = g.CP == 4 ? LATK(4, false, false) : LATK(5, false, false);
             else if (lat_planes && multi && g.CP == 4 && ceq && lattice_points(K, c) == 8)
                 rc = go(gram_levels_wide_kernel<4, 4, true, false, true, true, 8>);      // C5's lattice: approximate scores choose (lattice_fast)
+            else if (lat_planes && multi && g.CP == 4 && ceq && lattice_points(K, c) == 5)
+                rc = go(gram_levels_wide_kernel<4, 4, true, false, true, true, 5>);      // the released shape's
             else if (lat_planes) rc = multi ? (g.CP == 4 ? LATK(4, true, false) : LATK(5, true, false)) : (g.CP == 4 ? LATK(4, false, false) : LATK(5, false, false));
             else if (multi) rc = g.CP == 4 ? LATK(4, true, true) : LATK(5, true, true);
             else rc = g.CP == 4 ? LATK(4, false, true) : LATK(5, false, true);
